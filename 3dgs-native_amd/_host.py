@@ -1,0 +1,70 @@
+"""Host-side plumbing shared by forward.py and backward.py: tensor conversion, camera struct packing,
+workspace caching.  PyTorch is only the owner of device memory and streams here."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def device_of(*xs):
+    for x in xs:
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            return x.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("3dgs-native_amd needs a ROCm GPU (MI355X); no CPU path exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(x, dtype, dev, shape=None):
+    """numpy / torch / sequence -> contiguous device tensor (the reference's to_warp_array,
+    utils/wp_utils.py:34-44, minus the forced re-upload when the data is already resident)."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=dev, dtype=dtype)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(x)), device="cpu").to(dtype).to(dev)
+    if shape is not None:
+        t = t.reshape(shape)
+    return t.contiguous()
+
+
+def host_f32(x, n):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    a = np.asarray(x, dtype=np.float64).reshape(-1)[:n]
+    return a.astype(np.float32)
+
+
+def make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H):
+    cam = _lib.GsrCamera()
+    cam.view[:] = host_f32(viewmatrix, 16).tolist()    # float64 -> float32 once (reference forward.py:694-695)
+    cam.proj[:] = host_f32(projmatrix, 16).tolist()
+    cam.campos[:] = host_f32(campos, 3).tolist()
+    cam.bg[:] = host_f32(background, 3).tolist()
+    cam.tan_fovx, cam.tan_fovy = float(tan_fovx), float(tan_fovy)
+    cam.focal_x = W / (2.0 * float(tan_fovx))          # float64, rounded by the c_float store (quirk Q8)
+    cam.focal_y = H / (2.0 * float(tan_fovy))
+    cam.W, cam.H = int(W), int(H)
+    return cam
+
+
+_ws = {}
+
+
+def workspace(kind, nbytes, dev):
+    """Grow-only scratch buffer per (kind, device)."""
+    key = (kind, dev.index)
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+        _ws[key] = t
+    return t
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def stream_ptr(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

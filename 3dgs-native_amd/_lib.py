@@ -1,0 +1,89 @@
+"""
+ctypes binding of libgsr_hip.so (include/gsr.h).  The library is the only compute path: if it is
+missing this module raises -- there is no Python, torch or CPU fallback behind it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+GSR_OK, GSR_E_NULL, GSR_E_DIMS, GSR_E_OVERFLOW, GSR_E_WORKSPACE, GSR_E_HIP, GSR_E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+
+vp = C.c_void_p
+
+
+class GsrScene(C.Structure):
+    _fields_ = [("N", C.c_int64), ("means", vp), ("scales", vp), ("rotations", vp), ("opacity", vp), ("sh", vp),
+                ("sh_degree", C.c_int32), ("scale_modifier", C.c_float), ("clamped", C.c_int32)]
+
+
+class GsrCamera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("campos", C.c_float * 3), ("bg", C.c_float * 3),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("focal_x", C.c_float), ("focal_y", C.c_float),
+                ("W", C.c_int32), ("H", C.c_int32)]
+
+
+class GsrGeom(C.Structure):
+    _fields_ = [("radii", vp), ("tiles_touched", vp), ("point_offsets", vp), ("xy", vp), ("depths", vp), ("cov3D", vp),
+                ("rgb", vp), ("conic_opacity", vp), ("clamped_state", vp)]
+
+
+class GsrBinning(C.Structure):
+    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp)]
+
+
+class GsrImage(C.Structure):
+    _fields_ = [("image", vp), ("inv_depth", vp), ("final_T", vp), ("n_contrib", vp)]
+
+
+class GsrGrads(C.Structure):
+    _fields_ = [("dL_dmean3D", vp), ("dL_dscale", vp), ("dL_drot", vp), ("dL_dopacity", vp), ("dL_dshs", vp),
+                ("dL_dcolor", vp), ("dL_dmean2D", vp), ("dL_dconic", vp)]
+
+
+EXPORTS = {
+    "gsr_abi_version": (C.c_int, []),
+    "gsr_strerror": (C.c_char_p, [C.c_int]),
+    "gsr_geom_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gsr_binning_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "gsr_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "gsr_forward_count": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), vp, C.c_size_t,
+                                    C.POINTER(C.c_int64), vp]),
+    "gsr_forward_render": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
+                                     C.POINTER(GsrImage), vp, C.c_size_t, vp, C.c_size_t, vp]),
+    "gsr_backward": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
+                               C.POINTER(GsrImage), vp, C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libgsr_hip.so once.  Raises if it has not been built (`__graft_entry__.build()`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        if h.gsr_abi_version() != 1:
+            raise RuntimeError("libgsr_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def strerror(code):
+    return lib().gsr_strerror(code).decode()
+
+
+def check(code):
+    """Map a GSR_E_* return code to the exception the reference would raise."""
+    if code == GSR_OK:
+        return
+    if code == GSR_E_OVERFLOW:   # reference forward.py:765-767 raises ValueError
+        raise ValueError("Number of rendered points exceeds the maximum supported (2^30).")
+    raise RuntimeError(f"libgsr_hip: {strerror(code)} (code {code})")

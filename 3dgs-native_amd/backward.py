@@ -1,0 +1,89 @@
+"""
+backward(): the reference's gradient call surface (reference backward.py:955-1196) over the MI355X
+library.  Same keyword arguments and the same nine-key return dict (`dL_dcov3D` is all zeros, as in
+the reference, whose real dL/dSigma3D is a local that never leaves backward_preprocess, :812/:1119).
+The five optimizer gradients are views into one flat float32 arena (`_arena`, 59 floats per
+Gaussian: mean3D | scale | rot | opacity | shs) so data-parallel training reduces them with a single
+RCCL all-reduce.
+"""
+import ctypes as C
+
+import torch
+
+from . import _host, _lib
+
+
+def _get(buf, key):
+    if buf is None:
+        raise NameError(f"backward() needs the forward buffer holding '{key}' (the reference fails the same way, "
+                        "backward.py:1084-1090)")
+    return buf.get(key)
+
+
+def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=None, rotations=None, scale_modifier=1.0,
+             viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5, image_height=256, image_width=256, campos=None,
+             radii=None, means2D=None, conic_opacity=None, rgb=None, clamped=None, cov3Ds=None, geom_buffer=None,
+             binning_buffer=None, img_buffer=None, degree=3, debug=False):
+    L = _lib.lib()
+    dev = _host.device_of(means3D, dL_dpixels, shs, radii)
+    H, W = int(image_height), int(image_width)
+    f32, i32 = torch.float32, torch.int32
+    means = _host.to_dev(means3D, f32, dev, (-1, 3))
+    N = means.shape[0]
+    dpix = _host.to_dev(dL_dpixels, f32, dev, (H, W, 3))
+    sh = _host.to_dev(shs, f32, dev, (-1, 3))
+    sc = _host.to_dev(scales, f32, dev, (-1, 3))
+    rot = _host.to_dev(rotations, f32, dev, (-1, 4))
+    op = _host.to_dev(opacity, f32, dev, (-1,)) if opacity is not None else means.new_zeros((N,))  # unused (quirk Q7)
+    ranges = _get(img_buffer, "ranges")                       # reference backward.py:1084-1090
+    final_Ts = _get(img_buffer, "final_Ts")
+    n_contrib = _get(img_buffer, "n_contrib")
+    point_list = _get(binning_buffer, "point_list")
+    if geom_buffer is not None:                               # reference backward.py:1092-1103
+        radii = geom_buffer.get("radii") if radii is None else radii
+        means2D = geom_buffer.get("means2D") if means2D is None else means2D
+        conic_opacity = geom_buffer.get("conic_opacity") if conic_opacity is None else conic_opacity
+        rgb = geom_buffer.get("rgb") if rgb is None else rgb
+        clamped = geom_buffer.get("clamped_state") if clamped is None else clamped
+    radii = _host.to_dev(radii, i32, dev, (-1,))
+    m2d = _host.to_dev(means2D, f32, dev, (-1, 2))
+    con = _host.to_dev(conic_opacity, f32, dev, (-1, 4))
+    col = _host.to_dev(rgb, f32, dev, (-1, 3))
+    cl = _host.to_dev(clamped, f32, dev, (-1, 3))
+    c3 = _host.to_dev(cov3Ds, f32, dev, (-1, 6))
+    ranges = _host.to_dev(ranges, i32, dev, (-1, 2))
+    final_Ts = _host.to_dev(final_Ts, f32, dev, (H, W))
+    n_contrib = _host.to_dev(n_contrib, i32, dev, (H, W))
+    point_list = _host.to_dev(point_list, i32, dev, (-1,))
+    D = point_list.shape[0]
+    cam = _host.make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H)
+
+    scene = _lib.GsrScene(N, _host.ptr(means), _host.ptr(sc), _host.ptr(rot), _host.ptr(op), _host.ptr(sh), int(degree),
+                          float(scale_modifier), 1)
+    geom = _lib.GsrGeom(_host.ptr(radii), None, None, _host.ptr(m2d), None, _host.ptr(c3), _host.ptr(col), _host.ptr(con),
+                        _host.ptr(cl))
+    binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges))
+    img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
+
+    arena = torch.empty(N * 59, dtype=f32, device=dev)
+    o = [0, 3 * N, 6 * N, 10 * N, 11 * N, 59 * N]
+    dL_dmean3D = arena[o[0]:o[1]].view(N, 3)
+    dL_dscale = arena[o[1]:o[2]].view(N, 3)
+    dL_drot = arena[o[2]:o[3]].view(N, 4)
+    dL_dopacity = arena[o[3]:o[4]]
+    dL_dsh = arena[o[4]:o[5]].view(N * 16, 3)   # always N*16 rows: the reference under-allocates for degree < 3 (quirk Q6)
+    dL_dcolor = torch.empty((N, 3), dtype=f32, device=dev)
+    dL_dmean2D = torch.empty((N, 3), dtype=f32, device=dev)
+    dL_dconic = torch.empty((N, 4), dtype=f32, device=dev)
+    grads = _lib.GsrGrads(_host.ptr(dL_dmean3D), _host.ptr(dL_dscale), _host.ptr(dL_drot), _host.ptr(dL_dopacity),
+                          _host.ptr(dL_dsh), _host.ptr(dL_dcolor), _host.ptr(dL_dmean2D), _host.ptr(dL_dconic))
+    with torch.cuda.device(dev):
+        ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
+        _lib.check(L.gsr_backward(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
+                                  C.byref(grads), _host.ptr(ws), ws.numel(), _host.stream_ptr(dev)))
+    return {
+        "dL_dmean3D": dL_dmean3D, "dL_dcolor": dL_dcolor, "dL_dshs": dL_dsh, "dL_dopacity": dL_dopacity,
+        "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,
+        "dL_dcov3D": torch.zeros((N, 6), dtype=f32, device=dev),
+        "_arena": arena,
+    }

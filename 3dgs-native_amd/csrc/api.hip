@@ -1,0 +1,260 @@
+// api.hip -- the extern "C" entry points of libgsr_hip.so (include/gsr.h): argument checks, workspace
+// carving and the launch sequence of each stage.  No device memory is allocated here.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gsr_internal.h"
+
+extern int gsr_blend_p_override;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                                                         \
+    do {                                                                                                                      \
+        hipError_t e_ = (expr);                                                                                               \
+        if (e_ != hipSuccess) {                                                                                               \
+            fprintf(stderr, "libgsr_hip: %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(e_));       \
+            return GSR_E_HIP;                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
+
+struct Carver {
+    char *p;
+    size_t off = 0;
+    explicit Carver(void *base) : p((char *)base) {}
+    template <class T> T *take(size_t count)
+    {
+        T *r = (T *)(p ? p + off : nullptr);
+        off += gsr_align(count * sizeof(T));
+        return r;
+    }
+};
+
+int tile_bits(int tiles)
+{
+    int b = 1;
+    while ((1LL << b) < tiles) ++b;
+    return b;
+}
+
+struct BinWs {
+    uint64_t *sort_tmp;  // [N]  ping-pong partner of GeomWs::depth_item
+    int32_t *doff;       // [N]  exclusive offsets in depth order
+    int32_t *scan_tmp;   // block sums
+    int32_t *hist;       // [256 * nb]
+    int32_t *totals;     // [256]
+    uint64_t *tile_a;    // [D]
+    uint64_t *tile_b;    // [D]
+    size_t bytes;
+};
+BinWs carve_bin(void *base, int64_t N, int64_t D)
+{
+    Carver c(base);
+    BinWs w;
+    const int64_t m = N > D ? N : D;
+    w.sort_tmp = c.take<uint64_t>((size_t)N);
+    w.doff = c.take<int32_t>((size_t)N);
+    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_CHUNK) + 1);
+    w.hist = c.take<int32_t>(256 * ((size_t)gsr_div_up(m, GSR_RADIX_CHUNK) + 1));
+    w.totals = c.take<int32_t>(256);
+    w.tile_a = c.take<uint64_t>((size_t)D);
+    w.tile_b = c.take<uint64_t>((size_t)D);
+    w.bytes = c.off + 256;
+    return w;
+}
+
+struct BwdWs {
+    BlendRec *rec; // [N]
+    GradRec *acc;  // [N]
+    size_t bytes;
+};
+BwdWs carve_bwd(void *base, int64_t N)
+{
+    Carver c(base);
+    BwdWs w;
+    w.rec = c.take<BlendRec>((size_t)N);
+    w.acc = c.take<GradRec>((size_t)N);
+    w.bytes = c.off + 256;
+    return w;
+}
+
+int check_scene_cam(const GsrScene *sc, const GsrCamera *cam)
+{
+    if (!sc || !cam) return GSR_E_NULL;
+    if (sc->N < 0 || sc->N > 0x7FFFFFFFLL || cam->W <= 0 || cam->H <= 0 || sc->sh_degree < 0 || sc->sh_degree > 3) return GSR_E_DIMS;
+    if ((cam->W + 15) / 16 > 65535 || (cam->H + 15) / 16 > 65535) return GSR_E_DIMS;
+    if (sc->N > 0 && (!sc->means || !sc->scales || !sc->rotations || !sc->opacity || !sc->sh)) return GSR_E_NULL;
+    return GSR_OK;
+}
+
+CamK make_cam(const GsrCamera *c)
+{
+    CamK k;
+    memcpy(k.view, c->view, sizeof(k.view));
+    memcpy(k.proj, c->proj, sizeof(k.proj));
+    memcpy(k.campos, c->campos, sizeof(k.campos));
+    memcpy(k.bg, c->bg, sizeof(k.bg));
+    k.tan_fovx = c->tan_fovx;
+    k.tan_fovy = c->tan_fovy;
+    k.focal_x = c->focal_x;
+    k.focal_y = c->focal_y;
+    k.W = c->W;
+    k.H = c->H;
+    k.grid_x = (c->W + GSR_TILE - 1) / GSR_TILE;
+    k.grid_y = (c->H + GSR_TILE - 1) / GSR_TILE;
+    return k;
+}
+
+bool geom_ok(const GsrGeom *g)
+{
+    return g && g->radii && g->tiles_touched && g->point_offsets && g->xy && g->depths && g->cov3D && g->rgb && g->conic_opacity &&
+           g->clamped_state;
+}
+
+void read_tuning()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char *e = getenv("GSR_BLEND_P")) gsr_blend_p_override = atoi(e);
+}
+
+} // namespace
+
+GeomWs gsr_carve_geom(void *base, int64_t N)
+{
+    Carver c(base);
+    GeomWs w;
+    w.rec = c.take<BlendRec>((size_t)N);
+    w.rect = c.take<TileRect>((size_t)N);
+    w.depth_item = c.take<uint64_t>((size_t)N);
+    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_CHUNK) + 1);
+    w.bytes = c.off + 256;
+    return w;
+}
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+const char *gsr_strerror(int code)
+{
+    switch (code) {
+    case GSR_OK: return "ok";
+    case GSR_E_NULL: return "required pointer is null";
+    case GSR_E_DIMS: return "invalid dimensions or SH degree";
+    case GSR_E_OVERFLOW: return "Number of rendered points exceeds the maximum supported (2^30)";
+    case GSR_E_WORKSPACE: return "workspace missing or too small";
+    case GSR_E_HIP: return "HIP runtime error (see stderr)";
+    case GSR_E_CAPACITY: return "binning capacity does not match the rendered count";
+    default: return "unknown error";
+    }
+}
+
+size_t gsr_geom_workspace_bytes(int64_t N) { return gsr_carve_geom(nullptr, N < 0 ? 0 : N).bytes; }
+size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t, int32_t) { return carve_bin(nullptr, N < 0 ? 0 : N, D < 0 ? 0 : D).bytes; }
+size_t gsr_backward_workspace_bytes(int64_t N, int64_t, int32_t, int32_t) { return carve_bwd(nullptr, N < 0 ? 0 : N).bytes; }
+
+int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, void *geom_ws, size_t geom_ws_bytes,
+                      int64_t *num_rendered, void *stream)
+{
+    read_tuning();
+    if (int rc = check_scene_cam(scene, camera)) return rc;
+    if (!num_rendered) return GSR_E_NULL;
+    *num_rendered = 0;
+    const int64_t N = scene->N;
+    if (N == 0) return GSR_OK; // reference behaviour undefined (quirk Q10): empty buffers, D = 0
+    if (!geom_ok(geom)) return GSR_E_NULL;
+    if (!geom_ws || geom_ws_bytes < gsr_geom_workspace_bytes(N)) return GSR_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const CamK cam = make_cam(camera);
+    const GeomWs ws = gsr_carve_geom(geom_ws, N);
+    HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s));
+    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, s));
+    int32_t last = 0;
+    HIP_TRY(hipMemcpyAsync(&last, geom->point_offsets + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *num_rendered = (int64_t)last;
+    if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
+    return GSR_OK;
+}
+
+int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning,
+                       const GsrImage *image, void *geom_ws, size_t geom_ws_bytes, void *bin_ws, size_t bin_ws_bytes, void *stream)
+{
+    read_tuning();
+    if (int rc = check_scene_cam(scene, camera)) return rc;
+    if (!binning || !image || !image->image || !image->inv_depth || !image->final_T || !image->n_contrib || !binning->ranges)
+        return GSR_E_NULL;
+    const int64_t N = scene->N, D = binning->D;
+    if (D < 0 || D > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
+    hipStream_t s = (hipStream_t)stream;
+    const CamK cam = make_cam(camera);
+    const size_t P = (size_t)cam.W * cam.H;
+    const int tiles = cam.grid_x * cam.grid_y;
+    HIP_TRY(hipMemsetAsync(binning->ranges, 0, sizeof(int32_t) * 2 * tiles, s));
+    if (D == 0 || N == 0) { // reference skips the blend: zeros, not background (forward.py:830, quirk Q10)
+        HIP_TRY(hipMemsetAsync(image->image, 0, P * 3 * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(image->inv_depth, 0, P * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(image->final_T, 0, P * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(image->n_contrib, 0, P * sizeof(int32_t), s));
+        return GSR_OK;
+    }
+    if (!geom_ok(geom) || !binning->point_list) return GSR_E_NULL;
+    if (!geom_ws || geom_ws_bytes < gsr_geom_workspace_bytes(N)) return GSR_E_WORKSPACE;
+    if (!bin_ws || bin_ws_bytes < gsr_binning_workspace_bytes(N, D, cam.W, cam.H)) return GSR_E_WORKSPACE;
+    const GeomWs gw = gsr_carve_geom(geom_ws, N);
+    const BinWs bw = carve_bin(bin_ws, N, D);
+
+    // 1. Gaussians by depth bits (stable from id order): four 8-bit passes over the high word
+    uint64_t *src = gw.depth_item, *dst = bw.sort_tmp;
+    for (int pass = 0; pass < 4; ++pass) {
+        HIP_TRY(gsr_launch_radix_pass(src, dst, bw.hist, bw.totals, N, 32 + 8 * pass, s));
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    // 2. offsets in depth order, 3. expansion to (tile, id) items
+    HIP_TRY(gsr_launch_scan(geom->tiles_touched, src, bw.doff, bw.scan_tmp, N, 1, s));
+    HIP_TRY(gsr_launch_expand(src, bw.doff, gw.rect, bw.tile_a, N, cam.grid_x, s));
+    // 4. stable partition by tile id
+    uint64_t *tsrc = bw.tile_a, *tdst = bw.tile_b;
+    const int tb = tile_bits(tiles);
+    for (int shift = 0; shift < tb; shift += 8) {
+        HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, 32 + shift, s));
+        uint64_t *t = tsrc; tsrc = tdst; tdst = t;
+    }
+    // 5. point_list + ranges, 6. blend
+    HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, s));
+    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, s));
+    return GSR_OK;
+}
+
+int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning, const GsrImage *image,
+                 const float *dL_dpixels, const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream)
+{
+    read_tuning();
+    if (int rc = check_scene_cam(scene, camera)) return rc;
+    const int64_t N = scene->N;
+    if (N == 0) return GSR_OK;
+    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || !grads->dL_dshs ||
+        !grads->dL_dcolor || !grads->dL_dmean2D || !grads->dL_dconic)
+        return GSR_E_NULL;
+    if (!geom || !geom->radii || !geom->xy || !geom->cov3D || !geom->rgb || !geom->conic_opacity || !geom->clamped_state) return GSR_E_NULL;
+    if (!binning || !image || !dL_dpixels) return GSR_E_NULL;
+    const int64_t D = binning->D;
+    if (D < 0 || D > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
+    if (D > 0 && (!binning->point_list || !binning->ranges || !image->final_T || !image->n_contrib)) return GSR_E_NULL;
+    if (!ws || ws_bytes < gsr_backward_workspace_bytes(N, D, camera->W, camera->H)) return GSR_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const CamK cam = make_cam(camera);
+    const BwdWs bw = carve_bwd(ws, N);
+    HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
+    if (D > 0) {
+        HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));
+        HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
+    }
+    HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));
+    return GSR_OK;
+}
+
+} // extern "C"

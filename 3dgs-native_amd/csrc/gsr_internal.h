@@ -1,0 +1,75 @@
+// gsr_internal.h -- shared declarations for the gfx950 rasterizer kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr.h"
+
+#define GSR_WAVE 64
+
+// Camera constants passed by value to kernels (lands in SGPRs / kernarg).
+struct CamK {
+    float view[16];
+    float proj[16];
+    float campos[3];
+    float bg[3];
+    float tan_fovx, tan_fovy;
+    float focal_x, focal_y;
+    int W, H, grid_x, grid_y;
+};
+
+// Per-Gaussian blend record, 64 B = one cache sector per gather (geom workspace).
+//   f[0..1] xy, f[2..4] conic a,b,c, f[5] opacity, f[6..8] rgb, f[9] 1/depth, rest pad.
+struct __attribute__((aligned(16))) BlendRec {
+    float f[16];
+};
+
+// Packed tile rectangle of one Gaussian (min_x, min_y, max_x, max_y), all < 65536.
+struct __attribute__((aligned(8))) TileRect {
+    uint16_t x0, y0, x1, y1;
+};
+
+static inline int64_t gsr_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- layout of the geom workspace (persists from gsr_forward_count to gsr_forward_render) ----
+struct GeomWs {
+    BlendRec *rec;        // [N]
+    TileRect *rect;       // [N]
+    uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled
+    int32_t *scan_tmp;    // block sums for the id-order scan
+    size_t bytes;
+};
+GeomWs gsr_carve_geom(void *base, int64_t N);
+
+// ---- launchers (host functions; each enqueues on `s` and returns hipGetLastError()) ----
+hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s);
+
+// Device-wide scan of int32 (CHUNK items per block).  mode 0: out[i] = inclusive scan of in[i].
+// mode 1: values gathered through sorted depth items: v[k] = in[low32(items[k])], out = exclusive scan.
+#define GSR_SCAN_CHUNK 4096
+hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
+                           int64_t n, int mode, hipStream_t s);
+
+// One stable LSD radix pass on 64-bit items by the 8-bit digit at `shift`.
+#define GSR_RADIX_CHUNK 4096
+hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *hist /*[256*nb]*/, int32_t *totals /*[256]*/,
+                                 int64_t n, int shift, hipStream_t s);
+
+hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect,
+                             uint64_t *tile_items, int64_t n, int grid_x, hipStream_t s);
+hipError_t gsr_launch_ranges(const uint64_t *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D,
+                             hipStream_t s);
+hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
+                                    const BlendRec *rec, const GsrImage &img, hipStream_t s);
+
+// backward
+struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (atomics target)
+    float f[16];                              // 0..2 dcolor, 3..4 dmean2D, 5..7 dconic(a,b,c), 8 dopacity
+};
+hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s);
+hipError_t gsr_launch_blend_backward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
+                                     const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
+                                     GradRec *acc, hipStream_t s);
+hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc,
+                                    const GsrGrads &gr, hipStream_t s);

@@ -1,0 +1,234 @@
+// preprocess.hip -- per-Gaussian projection stage for gfx950.
+//
+// Computes what the reference's wp_preprocess does (forward.py:190-382: near cull, clip-space
+// projection, Sigma3D = R S S^T R^T, EWA Sigma2D, conic, 3-sigma radius, tile rectangle, SH colour)
+// with float operations in the same order as the CPU oracle (compiled with -ffp-contract=off), so the
+// integer outputs (radii, tile counts, depth bits -> sort order) agree exactly.  On top of the
+// reference's outputs it emits three internal products for the later stages:
+//   rec[i]        64-byte blend record (xy, conic, opacity, rgb, 1/depth): one sector per gather
+//   rect[i]       packed tile rectangle (so key duplication does not redo the float math)
+//   depth_item[i] (depth bits << 32 | i), the item the depth sort works on
+// One thread per Gaussian, 256 per workgroup; every output is written for every i (zeros for culled
+// Gaussians, quirk Q11), so no buffer needs pre-zeroing.
+#include "gsr_internal.h"
+
+namespace {
+
+struct M33 {
+    float m[3][3];
+};
+
+__device__ __forceinline__ M33 mul33(const M33 &a, const M33 &b)
+{
+    M33 t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += a.m[i][k] * b.m[k][j];
+            t.m[i][j] = s;
+        }
+    return t;
+}
+__device__ __forceinline__ M33 tr33(const M33 &a)
+{
+    M33 t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t.m[i][j] = a.m[j][i];
+    return t;
+}
+// (p,1) * M under the row-vector convention, rows accumulated in ascending order.
+__device__ __forceinline__ void rowvec_mul44(float px, float py, float pz, const float *M, float out[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r = M[j] * px;
+        r += M[4 + j] * py;
+        r += M[8 + j] * pz;
+        r += M[12 + j] * 1.0f;
+        out[j] = r;
+    }
+}
+__device__ __forceinline__ float ndc2pix(float x, float size) { return ((x + 1.0f) * size - 1.0f) * 0.5f; }
+
+__device__ __forceinline__ int f2i(float v) { return (int)v; } // v_cvt_i32_f32: truncation
+
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int64_t N, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
+    const float *__restrict__ opac, const float *__restrict__ shs, int degree, int clamped, float scale_mod, CamK cam,
+    int32_t *__restrict__ radii, float *__restrict__ xy, float *__restrict__ depths, float *__restrict__ cov3Ds,
+    float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
+    float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
+    uint64_t *__restrict__ depth_item)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+
+    // outputs, defaulting to the culled values
+    int o_radius = 0, o_tiles = 0;
+    float o_xy[2] = {0.0f, 0.0f}, o_depth = 0.0f, o_cov[6] = {0, 0, 0, 0, 0, 0}, o_rgb[3] = {0, 0, 0};
+    float o_con[4] = {0, 0, 0, 0}, o_cl[3] = {0, 0, 0};
+    TileRect o_rect = {0, 0, 0, 0};
+    bool visible = false;
+
+    const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+    float p_view[4];
+    rowvec_mul44(px, py, pz, cam.view, p_view);
+    if (!(p_view[2] < 0.2f)) {
+        float p_hom[4];
+        rowvec_mul44(px, py, pz, cam.proj, p_hom);
+        const float p_w = 1.0f / (p_hom[3] + 0.0000001f);
+        const float ndc_x = p_hom[0] * p_w, ndc_y = p_hom[1] * p_w;
+
+        // Sigma3D = (R S)(R S)^T, R's columns = quat_rotate(q, e_c)
+        const float sx = scale_mod * scales[3 * i], sy = scale_mod * scales[3 * i + 1], sz = scale_mod * scales[3 * i + 2];
+        const float4 q = *reinterpret_cast<const float4 *>(rots + 4 * i);
+        M33 R;
+        {
+            const float cs = 2.0f * q.w * q.w - 1.0f;
+            const float qv[3] = {q.x, q.y, q.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v[3] = {c == 0 ? 1.0f : 0.0f, c == 1 ? 1.0f : 0.0f, c == 2 ? 1.0f : 0.0f};
+                const float cr[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+                float d = qv[0] * v[0];
+                d += qv[1] * v[1];
+                d += qv[2] * v[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) R.m[r][c] = v[r] * cs + cr[r] * q.w * 2.0f + qv[r] * d * 2.0f;
+            }
+        }
+        const M33 S = {{{sx, 0.0f, 0.0f}, {0.0f, sy, 0.0f}, {0.0f, 0.0f, sz}}};
+        const M33 M = mul33(R, S);
+        const M33 sig = mul33(M, tr33(M));
+        o_cov[0] = sig.m[0][0]; o_cov[1] = sig.m[0][1]; o_cov[2] = sig.m[0][2];
+        o_cov[3] = sig.m[1][1]; o_cov[4] = sig.m[1][2]; o_cov[5] = sig.m[2][2];
+
+        // EWA projection.  T = J * W with W = view[0:3,0:3] as stored (quirk Q1: forward convention).
+        float t0, t1;
+        const float t2 = p_view[2];
+        {
+            const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+            const float txtz = p_view[0] / t2, tytz = p_view[1] / t2;
+            t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+            t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+        }
+        const float Wf = (float)cam.W, Hf = (float)cam.H;
+        const float focal_x = Wf / (2.0f * cam.tan_fovx), focal_y = Hf / (2.0f * cam.tan_fovy);
+        const M33 J = {{{focal_x / t2, 0.0f, -(focal_x * t0) / (t2 * t2)}, {0.0f, focal_y / t2, -(focal_y * t1) / (t2 * t2)}, {0.0f, 0.0f, 0.0f}}};
+        const M33 Wm = {{{cam.view[0], cam.view[1], cam.view[2]}, {cam.view[4], cam.view[5], cam.view[6]}, {cam.view[8], cam.view[9], cam.view[10]}}};
+        const M33 T = mul33(J, Wm);
+        const M33 Vrk = {{{o_cov[0], o_cov[1], o_cov[2]}, {o_cov[1], o_cov[3], o_cov[4]}, {o_cov[2], o_cov[4], o_cov[5]}}};
+        const M33 c2 = mul33(mul33(T, tr33(Vrk)), tr33(T));
+
+        const float cb0 = c2.m[0][0] + 0.3f, cb1 = c2.m[0][1], cb2 = c2.m[1][1] + 0.3f;
+        const float det = cb0 * cb2 - cb1 * cb1;
+        if (det != 0.0f) {
+            const float det_inv = 1.0f / det;
+            const float mid = 0.5f * (cb0 + cb2);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda1 = mid + sq, lambda2 = mid - sq;
+            const float my_radius = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float pim_x = ndc2pix(ndc_x, Wf), pim_y = ndc2pix(ndc_y, Hf);
+            const int rx0 = min(cam.grid_x, max(0, f2i((pim_x - my_radius) / 16.0f)));
+            const int ry0 = min(cam.grid_y, max(0, f2i((pim_y - my_radius) / 16.0f)));
+            const int rx1 = min(cam.grid_x, max(0, f2i((pim_x + my_radius + 16.0f - 1.0f) / 16.0f)));
+            const int ry1 = min(cam.grid_y, max(0, f2i((pim_y + my_radius + 16.0f - 1.0f) / 16.0f)));
+            const int tiles = (ry1 - ry0) * (rx1 - rx0);
+            if (tiles != 0) {
+                visible = true;
+                // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian
+                const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+                float l2 = dx * dx;
+                l2 += dy * dy;
+                l2 += dz * dz;
+                const float len = sqrtf(l2);
+                float x = 0.0f, y = 0.0f, z = 0.0f;
+                if (len > 0.0f) { x = dx / len; y = dy / len; z = dz / len; }
+                float sh[48];
+                const float4 *shp = reinterpret_cast<const float4 *>(shs + (size_t)i * 48);
+                const int nload = degree == 0 ? 1 : (degree == 1 ? 3 : (degree == 2 ? 7 : 12));
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < nload) v = shp[k];
+                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+                }
+                const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+                const float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#define SHC(k) sh[(k) * 3 + c]
+                    float r = SH_C0 * SHC(0);
+                    if (degree > 0) {
+                        r = r - SH_C1 * y * SHC(1) + SH_C1 * z * SHC(2) - SH_C1 * x * SHC(3);
+                        if (degree > 1) {
+                            r = r + 1.0925484305920792f * xy_ * SHC(4);
+                            r = r + (-1.0925484305920792f) * yz * SHC(5);
+                            r = r + 0.31539156525252005f * (2.0f * zz - xx - yy) * SHC(6);
+                            r = r + (-1.0925484305920792f) * xz * SHC(7);
+                            r = r + 0.5462742152960396f * (xx - yy) * SHC(8);
+                            if (degree > 2) {
+                                r = r + (-0.5900435899266435f) * y * (3.0f * xx - yy) * SHC(9);
+                                r = r + 2.890611442640554f * xy_ * z * SHC(10);
+                                r = r + (-0.4570457994644658f) * y * (4.0f * zz - xx - yy) * SHC(11);
+                                r = r + 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHC(12);
+                                r = r + (-0.4570457994644658f) * x * (4.0f * zz - xx - yy) * SHC(13);
+                                r = r + 1.445305721320277f * z * (xx - yy) * SHC(14);
+                                r = r + (-0.5900435899266435f) * x * (xx - 3.0f * yy) * SHC(15);
+                            }
+                        }
+                    }
+#undef SHC
+                    r = r + 0.5f;
+                    o_cl[c] = r < 0.0f ? 1.0f : 0.0f;
+                    if (clamped) r = fmaxf(r, 0.0f);
+                    o_rgb[c] = r;
+                }
+                o_depth = p_view[2];
+                o_radius = f2i(my_radius);
+                o_xy[0] = pim_x; o_xy[1] = pim_y;
+                o_con[0] = cb2 * det_inv; o_con[1] = -cb1 * det_inv; o_con[2] = cb0 * det_inv; o_con[3] = opac[i];
+                o_tiles = tiles;
+                o_rect.x0 = (uint16_t)rx0; o_rect.y0 = (uint16_t)ry0; o_rect.x1 = (uint16_t)rx1; o_rect.y1 = (uint16_t)ry1;
+            }
+        }
+    }
+
+    radii[i] = o_radius;
+    tiles_touched[i] = o_tiles;
+    *reinterpret_cast<float2 *>(xy + 2 * i) = make_float2(o_xy[0], o_xy[1]);
+    depths[i] = o_depth;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<float2 *>(cov3Ds + 6 * i + 2 * k) = make_float2(o_cov[2 * k], o_cov[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rgb[3 * i + k] = o_rgb[k]; clamped_state[3 * i + k] = o_cl[k]; }
+    *reinterpret_cast<float4 *>(conic_opacity + 4 * i) = make_float4(o_con[0], o_con[1], o_con[2], o_con[3]);
+
+    // internal products
+    float4 *rp = reinterpret_cast<float4 *>(rec + i);
+    const float inv_depth = visible ? 1.0f / o_depth : 0.0f;
+    rp[0] = make_float4(o_xy[0], o_xy[1], o_con[0], o_con[1]);
+    rp[1] = make_float4(o_con[2], o_con[3], o_rgb[0], o_rgb[1]);
+    rp[2] = make_float4(o_rgb[2], inv_depth, 0.0f, 0.0f);
+    rect[i] = o_rect;
+    const uint32_t dbits = visible ? __float_as_uint(o_depth) : 0xFFFFFFFFu;
+    depth_item[i] = ((uint64_t)dbits << 32) | (uint64_t)(uint32_t)i;
+}
+
+} // namespace
+
+hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s)
+{
+    if (sc.N == 0) return hipSuccess;
+    const int threads = 256;
+    const unsigned blocks = (unsigned)gsr_div_up(sc.N, threads);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
+                       sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
+                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item);
+    return hipGetLastError();
+}

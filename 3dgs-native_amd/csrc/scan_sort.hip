@@ -1,0 +1,329 @@
+// scan_sort.hip -- binning stage for gfx950: scans, stable radix passes, key expansion, tile ranges.
+//
+// The reference builds one (tile << 32 | depth bits) int64 key per (Gaussian, tile) pair in id order
+// and sorts all of them with an 8-pass 64-bit radix sort (forward.py:518-558, :791-824).  The result
+// is the list ordered by (tile, depth bits, id) -- ties broken by id because the sort is stable and
+// pairs are emitted in id order (quirk Q13).  We produce the SAME list with much less HBM traffic:
+//   1. sort the N Gaussians once by depth bits (stable, from id order)      -> order (depth, id)
+//   2. expand them to (tile << 32 | id) items in that order                  -> order (depth, id) per tile
+//   3. stable-partition the D items by tile id only (ceil(log2(tiles)/8) passes instead of 8)
+// All sorting is one kernel family: a stable LSD radix pass over 64-bit items on an 8-bit digit.
+// Wave64 ballots give each item its rank among equal digits (no per-item atomics), an LDS reorder
+// makes the scatter write contiguous runs.  No inter-workgroup spin-waits anywhere: every dependency
+// is a kernel boundary.
+#include "gsr_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// wave / block scan helpers (wave64)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// Inclusive scan of one int per thread across a 256-thread block; *total gets the block sum.
+__device__ __forceinline__ int block_incl_scan_256(int v, int *lds4 /* >= 4 ints */, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int s = wave_incl_scan(v);
+    if (lane == 63) lds4[w] = s;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int c = lds4[k];
+        if (k < w) add += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return s + add;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-wide scan: reduce -> single-block scan of block sums -> rescan with offsets
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = GSR_SCAN_CHUNK / 256; // items per thread (blocked arrangement)
+
+template <int MODE>
+__device__ __forceinline__ int scan_load(const int32_t *__restrict__ in, const uint64_t *__restrict__ items, int64_t k, int64_t n)
+{
+    if (k >= n) return 0;
+    if (MODE == 0) return in[k];
+    return in[(uint32_t)items[k]];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restrict__ in, const uint64_t *__restrict__ items,
+                                                          int32_t *__restrict__ block_sums, int64_t n)
+{
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_CHUNK;
+    int s = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) s += scan_load<MODE>(in, items, base + r * 256 + threadIdx.x, n);
+    int tot;
+    block_incl_scan_256(s, lds, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// exclusive scan of block_sums[0..nb) in place, one 256-thread block looping over 256-wide slabs
+__global__ __launch_bounds__(256) void scan_mid_kernel(int32_t *__restrict__ block_sums, int nb)
+{
+    __shared__ int lds[4];
+    int carry = 0;
+    for (int base = 0; base < nb; base += 256) {
+        const int k = base + threadIdx.x;
+        const int v = k < nb ? block_sums[k] : 0;
+        int tot;
+        const int inc = block_incl_scan_256(v, lds, &tot);
+        if (k < nb) block_sums[k] = carry + inc - v;
+        carry += tot;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const uint64_t *__restrict__ items,
+                                                         const int32_t *__restrict__ block_sums, int32_t *__restrict__ out, int64_t n)
+{
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) {
+        v[r] = scan_load<MODE>(in, items, base + r, n);
+        s += v[r];
+    }
+    int tot;
+    const int inc = block_incl_scan_256(s, lds, &tot);
+    int run = block_sums[blockIdx.x] + inc - s; // exclusive prefix of this thread's first item
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) {
+        if (MODE == 0) { run += v[r]; if (base + r < n) out[base + r] = run; }      // inclusive
+        else { if (base + r < n) out[base + r] = run; run += v[r]; }                 // exclusive
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stable radix pass (8-bit digit) on 64-bit items
+// ---------------------------------------------------------------------------------------------
+constexpr int RADIX_ITEMS = GSR_RADIX_CHUNK / 256; // rounds per wave (each wave owns 64*RADIX_ITEMS consecutive items)
+
+// block histogram of the digit; hist is digit-major [256][nb]
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restrict__ in, int32_t *__restrict__ hist, int64_t n,
+                                                         int shift, int nb)
+{
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * GSR_RADIX_CHUNK;
+#pragma unroll 4
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+        const int64_t k = base + r * 256 + threadIdx.x;
+        if (k < n) atomicAdd(&h[(int)((in[k] >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+// one block per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ totals, int nb)
+{
+    __shared__ int lds[4];
+    int32_t *row = hist + (size_t)blockIdx.x * nb;
+    int carry = 0;
+    for (int base = 0; base < nb; base += 256) {
+        const int k = base + threadIdx.x;
+        const int v = k < nb ? row[k] : 0;
+        int tot;
+        const int inc = block_incl_scan_256(v, lds, &tot);
+        if (k < nb) row[k] = carry + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                            const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
+                                                            int64_t n, int shift, int nb)
+{
+    __shared__ uint64_t s_items[GSR_RADIX_CHUNK]; // 32 KiB: items reordered by digit
+    __shared__ int s_wcnt[4][256];                 // per-wave digit counts -> per-wave start offsets
+    __shared__ int s_dstart[256];                  // first LDS slot of each digit
+    __shared__ int s_gbase[256];                   // global position of the block's first item of each digit
+    __shared__ int s_tmp[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t block_base = (int64_t)blockIdx.x * GSR_RADIX_CHUNK;
+    const int64_t wave_base = block_base + (int64_t)w * 64 * RADIX_ITEMS;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_wcnt[k][tid] = 0;
+    __syncthreads();
+
+    // pass 1: rank every item among equal digits of its wave, in index order
+    uint64_t item[RADIX_ITEMS];
+    int rank[RADIX_ITEMS]; // rank within (wave, digit)
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+        const int64_t k = wave_base + r * 64 + lane;
+        const bool valid = k < n;
+        item[r] = valid ? in[k] : ~0ull;
+        const int d = (int)((item[r] >> shift) & 255);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        if (!valid) peers = 0ull; // invalid lanes rank nothing
+        const int before = __popcll(peers & lt_mask);
+        const int count = __popcll(peers);
+        int old = 0;
+        const int leader = peers ? __ffsll((long long)peers) - 1 : 0;
+        if (valid && lane == leader) {
+            old = s_wcnt[w][d];
+            s_wcnt[w][d] = old + count;
+        }
+        old = __shfl(old, leader, 64);
+        rank[r] = old + before;
+    }
+    __syncthreads();
+
+    // per digit: prefix over the 4 waves, block total, then exclusive scan over digits
+    {
+        const int d = tid;
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = s_wcnt[k][d];
+            s_wcnt[k][d] = run;
+            run += c;
+        }
+        int tot;
+        const int inc = block_incl_scan_256(run, s_tmp, &tot);
+        s_dstart[d] = inc - run;
+        // digit base over the whole array = sum of totals of smaller digits
+        const int tinc = block_incl_scan_256(totals[d], s_tmp, &tot);
+        s_gbase[d] = tinc - totals[d] + hist[(size_t)d * nb + blockIdx.x];
+    }
+    __syncthreads();
+
+    // pass 2: reorder in LDS by digit (stable)
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+        const int64_t k = wave_base + r * 64 + lane;
+        if (k < n) {
+            const int d = (int)((item[r] >> shift) & 255);
+            s_items[s_dstart[d] + s_wcnt[w][d] + rank[r]] = item[r];
+        }
+    }
+    __syncthreads();
+
+    // pass 3: contiguous runs out to global memory
+    const int valid_n = (int)((n - block_base) < GSR_RADIX_CHUNK ? (n - block_base) : GSR_RADIX_CHUNK);
+#pragma unroll 4
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+        const int slot = r * 256 + tid;
+        if (slot < valid_n) {
+            const uint64_t it = s_items[slot];
+            const int d = (int)((it >> shift) & 255);
+            out[(int64_t)s_gbase[d] + (slot - s_dstart[d])] = it;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// expansion: depth-ordered Gaussians -> (tile << 32 | id) items, row-major tile walk
+// (same walk as reference forward.py:546-548: y outer, x inner)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ doff,
+                                                     const TileRect *__restrict__ rect, uint64_t *__restrict__ tile_items, int64_t n,
+                                                     int grid_x)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t it = sorted[k];
+    if ((uint32_t)(it >> 32) == 0xFFFFFFFFu) return; // culled (sorted to the end)
+    const uint32_t id = (uint32_t)it;
+    const TileRect rc = rect[id];
+    int64_t o = doff[k];
+    for (int y = rc.y0; y < rc.y1; ++y)
+        for (int x = rc.x0; x < rc.x1; ++x) tile_items[o++] = ((uint64_t)(uint32_t)(y * grid_x + x) << 32) | id;
+}
+
+// sorted tile items -> point_list + tile ranges (reference forward.py:561-586); ranges pre-zeroed
+__global__ __launch_bounds__(256) void ranges_kernel(const uint64_t *__restrict__ items, int32_t *__restrict__ point_list,
+                                                     int32_t *__restrict__ ranges, int64_t D)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= D) return;
+    const uint64_t it = items[idx];
+    point_list[idx] = (int32_t)(uint32_t)it;
+    const uint32_t cur = (uint32_t)(it >> 32);
+    if (idx == 0) ranges[2 * cur] = 0;
+    else {
+        const uint32_t prev = (uint32_t)(items[idx - 1] >> 32);
+        if (cur != prev) {
+            ranges[2 * prev + 1] = (int32_t)idx;
+            ranges[2 * cur] = (int32_t)idx;
+        }
+    }
+    if (idx == D - 1) ranges[2 * cur + 1] = (int32_t)D;
+}
+
+} // namespace
+
+hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
+                           hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const int nb = (int)gsr_div_up(n, GSR_SCAN_CHUNK);
+    if (mode == 0) {
+        hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, n);
+        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nb);
+        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, out, n);
+    } else {
+        hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, n);
+        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nb);
+        hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, out, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
+                                 hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, totals, nb);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, uint64_t *tile_items,
+                             int64_t n, int grid_x, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)gsr_div_up(n, 256)), dim3(256), 0, s, sorted_depth_items, doff, rect, tile_items,
+                       n, grid_x);
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_ranges(const uint64_t *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, hipStream_t s)
+{
+    if (D <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)gsr_div_up(D, 256)), dim3(256), 0, s, sorted_tile_items, point_list, ranges, D);
+    return hipGetLastError();
+}

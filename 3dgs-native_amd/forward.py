@@ -1,0 +1,67 @@
+"""
+render_gaussians(): the reference's forward call surface (reference forward.py:629-894) over the
+MI355X library.  Same keyword arguments, same (image, depth, dict) return with the same dict keys;
+arrays come back as torch tensors on the GPU instead of wp.array (callers do `.cpu().numpy()`).
+"""
+import ctypes as C
+
+import torch
+
+from . import _host, _lib
+from .config import TILE_M, TILE_N
+
+
+def render_gaussians(background, means3D, colors=None, opacity=None, scales=None, rotations=None, scale_modifier=1.0,
+                     viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5, image_height=256, image_width=256,
+                     sh=None, degree=3, campos=None, prefiltered=False, antialiasing=False, clamped=True, debug=False):
+    """Render 3D Gaussians.  `colors`, `prefiltered`, `antialiasing` are accepted and ignored exactly as in
+    the reference.  Returns (image (H,W,3) f32, inverse-depth (H,W) f32, buffers)."""
+    L = _lib.lib()
+    dev = _host.device_of(means3D, sh, opacity, scales, rotations)
+    H, W = int(image_height), int(image_width)
+    f32, i32 = torch.float32, torch.int32
+    means = _host.to_dev(means3D, f32, dev, (-1, 3))
+    N = means.shape[0]
+    shs = _host.to_dev(sh, f32, dev, (-1, 3))                 # reference forward.py:687
+    if shs.shape[0] != N * 16:
+        raise ValueError(f"sh must hold 16 coefficients per Gaussian (got {shs.shape[0]} rows for N={N})")
+    op = _host.to_dev(opacity, f32, dev, (-1,))               # (N,1) -> (N,)  utils/wp_utils.py:42-43
+    sc = _host.to_dev(scales, f32, dev, (-1, 3))
+    rot = _host.to_dev(rotations, f32, dev, (-1, 4))
+    if not (op.shape[0] == sc.shape[0] == rot.shape[0] == N):
+        raise ValueError("means3D, opacity, scales and rotations disagree on the number of Gaussians")
+    cam = _host.make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H)
+    gx, gy = (W + TILE_M - 1) // TILE_M, (H + TILE_N - 1) // TILE_N
+
+    scene = _lib.GsrScene(N, _host.ptr(means), _host.ptr(sc), _host.ptr(rot), _host.ptr(op), _host.ptr(shs),
+                          int(degree), float(scale_modifier), 1 if clamped else 0)
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    radii, tiles_touched, point_offsets = e((N,), i32), e((N,), i32), e((N,), i32)
+    xy, depths, cov3Ds, rgb = e((N, 2), f32), e((N,), f32), e((N, 6), f32), e((N, 3), f32)
+    conic_opacity, clamped_state = e((N, 4), f32), e((N, 3), f32)
+    geom = _lib.GsrGeom(_host.ptr(radii), _host.ptr(tiles_touched), _host.ptr(point_offsets), _host.ptr(xy), _host.ptr(depths),
+                        _host.ptr(cov3Ds), _host.ptr(rgb), _host.ptr(conic_opacity), _host.ptr(clamped_state))
+    image, depth_image = e((H, W, 3), f32), e((H, W), f32)
+    final_Ts, n_contrib = e((H, W), f32), e((H, W), i32)
+    img = _lib.GsrImage(_host.ptr(image), _host.ptr(depth_image), _host.ptr(final_Ts), _host.ptr(n_contrib))
+    ranges = e((gx * gy, 2), i32)
+    stream = _host.stream_ptr(dev)
+
+    with torch.cuda.device(dev):
+        gws = _host.workspace("geom", L.gsr_geom_workspace_bytes(N), dev)
+        D = C.c_int64(0)
+        _lib.check(L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), _host.ptr(gws), gws.numel(),
+                                       C.byref(D), stream))
+        D = D.value
+        if debug:
+            print(f"gsr: {W}x{H}, N={N}, D={D}, SH degree {degree}")
+        point_list = e((D,), i32)
+        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges))
+        bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
+        _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
+                                        _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
+    return image, depth_image, {
+        "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
+        "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,
+        "final_Ts": final_Ts, "n_contrib": n_contrib, "clamped_state": clamped_state,
+    }

@@ -1,0 +1,155 @@
+/*
+ * gsr.h -- C ABI of libgsr_hip.so, the MI355X (gfx950) 3D-Gaussian-Splatting rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of zhujinchong/3DGS-native.  The reference has no
+ * native FFI of its own: its "operator API" is two Python functions,
+ *     render_gaussians(...)   reference forward.py:629-894
+ *     backward(...)           reference backward.py:955-1196
+ * which launch Warp kernels.  The entry points below are what a binding for that pair calls instead
+ * of wp.launch (INTEGRATION.md shows the ctypes stub); 3dgs-native_amd/forward.py and backward.py are
+ * that binding, with the reference's keyword arguments and return-dict keys.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless marked host.  The caller owns all memory, including
+ *     scratch (one byte buffer per call, sized by the *_workspace_bytes functions).  The library
+ *     never allocates or frees device memory and keeps no global state, so it is re-entrant for
+ *     distinct buffers.  One process per GPU for multi-GPU use.
+ *   - All work is enqueued on `stream` (a hipStream_t).  Only gsr_forward_count synchronises (it
+ *     returns the number of (tile, Gaussian) pairs D, which sizes GsrBinning -- the reference's one
+ *     unavoidable readback, forward.py:764).
+ *   - Layouts are the reference's packed AoS: vec3 = 3 floats, vec4 = 4 floats, VEC6 = 6 floats
+ *     (xx,xy,xz,yy,yz,zz; reference forward.py:186), images row-major [y][x].  Quaternions are
+ *     (x,y,z,w) (forward.py:177).  Matrices are 16 floats row-major AS STORED by the reference's
+ *     callers, used under the row-vector convention p' = p * M.
+ *   - Tiles are 16x16 pixels (reference config.py:21-22).
+ *   - Return value: GSR_OK or a negative GSR_E_* code; gsr_strerror() names it.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+#define GSR_TILE 16
+#define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
+#define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
+
+enum {
+    GSR_OK = 0,
+    GSR_E_NULL = -1,      /* a required pointer is null */
+    GSR_E_DIMS = -2,      /* N < 0, W/H <= 0, sh_degree outside 0..3, ... */
+    GSR_E_OVERFLOW = -3,  /* D > GSR_MAX_RENDERED (reference raises ValueError, forward.py:765) */
+    GSR_E_WORKSPACE = -4, /* workspace null or smaller than *_workspace_bytes(...) */
+    GSR_E_HIP = -5,       /* a HIP runtime call or kernel launch failed */
+    GSR_E_CAPACITY = -6   /* GsrBinning.D does not match the count returned by gsr_forward_count */
+};
+
+/* Inputs of wp_preprocess (reference forward.py:190-211). */
+typedef struct GsrScene {
+    int64_t N;              /* number of Gaussians */
+    const float *means;     /* [N*3]  world positions */
+    const float *scales;    /* [N*3]  raw scales (no activation, quirk Q5) */
+    const float *rotations; /* [N*4]  quaternions (x,y,z,w) */
+    const float *opacity;   /* [N]    raw opacities */
+    const float *sh;        /* [N*16*3] SH coefficients, stride 16 whatever the degree (quirk Q6) */
+    int32_t sh_degree;      /* 0..3 */
+    float scale_modifier;
+    int32_t clamped;        /* clamp SH colour at 0 (forward.py:364-370) */
+} GsrScene;
+
+/* Camera of one view (reference forward.py:694-700, :734-739). */
+typedef struct GsrCamera {
+    float view[16];   /* `viewmatrix` flattened row-major, as the caller stores it */
+    float proj[16];   /* `projmatrix` (full projection) flattened row-major */
+    float campos[3];
+    float bg[3];
+    float tan_fovx, tan_fovy;
+    float focal_x, focal_y; /* backward only: W/(2 tan_fovx), H/(2 tan_fovy) formed in float64 on the
+                               host and rounded once (reference backward.py:1044-1045, quirk Q8);
+                               the forward recomputes focal lengths in float32 (forward.py:115-116) */
+    int32_t W, H;
+} GsrCamera;
+
+/* Per-Gaussian outputs of the forward pass: the reference's returned dict entries
+ * radii / point_offsets / points_xy_image / depths / cov3Ds / colors / conic_opacity / clamped_state
+ * (forward.py:881-894) plus tiles_touched.  Culled Gaussians get zeros (quirk Q11). */
+typedef struct GsrGeom {
+    int32_t *radii;         /* [N] */
+    int32_t *tiles_touched; /* [N] */
+    int32_t *point_offsets; /* [N] inclusive scan of tiles_touched (utils/wp_utils.py:47-60) */
+    float *xy;              /* [N*2] */
+    float *depths;          /* [N] */
+    float *cov3D;           /* [N*6] */
+    float *rgb;             /* [N*3] */
+    float *conic_opacity;   /* [N*4] */
+    float *clamped_state;   /* [N*3] */
+} GsrGeom;
+
+/* Sorted (tile, depth) list: dict entries point_list / ranges. */
+typedef struct GsrBinning {
+    int64_t D;           /* number of (tile, Gaussian) pairs, from gsr_forward_count */
+    int32_t *point_list; /* [D] Gaussian ids sorted by (tile, depth bits, id) */
+    int32_t *ranges;     /* [tiles*2] (start,end) per tile, (0,0) for untouched tiles */
+} GsrBinning;
+
+/* Per-pixel outputs: image, inverse-depth image, dict entries final_Ts / n_contrib. */
+typedef struct GsrImage {
+    float *image;       /* [H*W*3] */
+    float *inv_depth;   /* [H*W] */
+    float *final_T;     /* [H*W] */
+    int32_t *n_contrib; /* [H*W] */
+} GsrImage;
+
+/* Gradients: the returned dict of backward() (reference backward.py:1185-1196).  The first five may
+ * alias one contiguous arena [3N | 3N | 4N | N | 48N] (a single RCCL all-reduce covers it).  Every
+ * array is fully written by gsr_backward (no pre-zeroing needed). */
+typedef struct GsrGrads {
+    float *dL_dmean3D;  /* [N*3] */
+    float *dL_dscale;   /* [N*3] */
+    float *dL_drot;     /* [N*4] (x,y,z,w) */
+    float *dL_dopacity; /* [N] */
+    float *dL_dshs;     /* [N*16*3] */
+    float *dL_dcolor;   /* [N*3] */
+    float *dL_dmean2D;  /* [N*3] (z = 0) */
+    float *dL_dconic;   /* [N*4] (a, b, 0, c) */
+} GsrGrads;
+
+int gsr_abi_version(void);
+const char *gsr_strerror(int code);
+
+/* Scratch sizes in bytes (host-side arithmetic only). */
+size_t gsr_geom_workspace_bytes(int64_t N);
+size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
+size_t gsr_backward_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
+
+/* Stage 1 of render_gaussians: wp_preprocess + wp_prefix_sum + the D readback
+ * (reference forward.py:719-767).  Fills *geom, leaves per-Gaussian blend records and depth keys in
+ * geom_ws (which must be passed unchanged to gsr_forward_render), and returns D in *num_rendered
+ * (host pointer).  Synchronises `stream`.  GSR_E_OVERFLOW if D > GSR_MAX_RENDERED. */
+int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom,
+                      void *geom_ws, size_t geom_ws_bytes, int64_t *num_rendered, void *stream);
+
+/* Stage 2 of render_gaussians: key duplication, sort, tile ranges, blend
+ * (reference forward.py:770-879).  binning->D must equal the count from stage 1.  With D == 0 the
+ * image and per-pixel buffers are zero-filled, not background (quirk Q10). */
+int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom,
+                       const GsrBinning *binning, const GsrImage *image, void *geom_ws,
+                       size_t geom_ws_bytes, void *bin_ws, size_t bin_ws_bytes, void *stream);
+
+/* backward(): wp_render_backward_kernel + the four per-Gaussian kernels
+ * (reference backward.py:890-953, :770-888).  dL_dpixels is [H*W*3].  Reads xy / conic_opacity / rgb /
+ * radii / cov3D / clamped_state from *geom and point_list / ranges / final_T / n_contrib from
+ * *binning / *image. */
+int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom,
+                 const GsrBinning *binning, const GsrImage *image, const float *dL_dpixels,
+                 const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */
