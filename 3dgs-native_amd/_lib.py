@@ -54,7 +54,12 @@ EXPORTS = {
                                      C.POINTER(GsrImage), vp, C.c_size_t, vp, C.c_size_t, vp]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
                                C.POINTER(GsrImage), vp, C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
+    "gsr_stage_timing": (C.c_int, [C.c_int, C.c_int]),
+    "gsr_stage_times": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
+
+STAGES = ["preprocess", "scan", "count_sync", "depth_sort", "depth_scan", "expand", "tile_sort", "ranges", "blend_fwd",
+          "bwd_prep", "blend_bwd", "geom_bwd"]
 
 _lib = None
 
@@ -87,3 +92,15 @@ def check(code):
     if code == GSR_E_OVERFLOW:   # reference forward.py:765-767 raises ValueError
         raise ValueError("Number of rendered points exceeds the maximum supported (2^30).")
     raise RuntimeError(f"libgsr_hip: {strerror(code)} (code {code})")
+
+
+def stage_timing(enable, max_steps=256):
+    check(lib().gsr_stage_timing(1 if enable else 0, int(max_steps)))
+
+
+def stage_times():
+    """Average ms per stage over the steps recorded since stage_timing(True); synchronise first."""
+    arr = (C.c_float * len(STAGES))()
+    n = C.c_int(0)
+    check(lib().gsr_stage_times(arr, C.byref(n)))
+    return {k: float(arr[i]) for i, k in enumerate(STAGES)}, n.value

@@ -112,6 +112,21 @@ bool geom_ok(const GsrGeom *g)
            g->clamped_state;
 }
 
+// ---- stage timing (profiling aid) ----
+struct StageTimer {
+    bool on = false;
+    int max_steps = 0, fwd_step = 0, bwd_step = 0;
+    hipEvent_t *ev = nullptr; // [max_steps][GSR_NSTAGES + 3]
+    static constexpr int PER = GSR_NSTAGES + 3;
+    hipEvent_t &at(int step, int k) { return ev[(size_t)step * PER + k]; }
+} g_timer;
+// event slots: 0..9 forward boundaries (before stage 0 .. after stage 8, with slot 3 = after sync),
+// 10..13 backward boundaries
+inline void mark(int step, int slot, hipStream_t s)
+{
+    if (g_timer.on && step < g_timer.max_steps) (void)hipEventRecord(g_timer.at(step, slot), s);
+}
+
 void read_tuning()
 {
     static bool done = false;
@@ -170,8 +185,12 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     hipStream_t s = (hipStream_t)stream;
     const CamK cam = make_cam(camera);
     const GeomWs ws = gsr_carve_geom(geom_ws, N);
+    const int st = g_timer.fwd_step;
+    mark(st, 0, s);
     HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s));
+    mark(st, 1, s);
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, s));
+    mark(st, 2, s);
     int32_t last = 0;
     HIP_TRY(hipMemcpyAsync(&last, geom->point_offsets + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -207,15 +226,20 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const GeomWs gw = gsr_carve_geom(geom_ws, N);
     const BinWs bw = carve_bin(bin_ws, N, D);
 
+    const int st = g_timer.fwd_step;
+    mark(st, 3, s);
     // 1. Gaussians by depth bits (stable from id order): four 8-bit passes over the high word
     uint64_t *src = gw.depth_item, *dst = bw.sort_tmp;
     for (int pass = 0; pass < 4; ++pass) {
         HIP_TRY(gsr_launch_radix_pass(src, dst, bw.hist, bw.totals, N, 32 + 8 * pass, s));
         uint64_t *t = src; src = dst; dst = t;
     }
+    mark(st, 4, s);
     // 2. offsets in depth order, 3. expansion to (tile, id) items
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, src, bw.doff, bw.scan_tmp, N, 1, s));
+    mark(st, 5, s);
     HIP_TRY(gsr_launch_expand(src, bw.doff, gw.rect, bw.tile_a, N, cam.grid_x, s));
+    mark(st, 6, s);
     // 4. stable partition by tile id
     uint64_t *tsrc = bw.tile_a, *tdst = bw.tile_b;
     const int tb = tile_bits(tiles);
@@ -223,9 +247,13 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
         HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, 32 + shift, s));
         uint64_t *t = tsrc; tsrc = tdst; tdst = t;
     }
+    mark(st, 7, s);
     // 5. point_list + ranges, 6. blend
     HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, s));
+    mark(st, 8, s);
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, s));
+    mark(st, 9, s);
+    if (g_timer.on) ++g_timer.fwd_step;
     return GSR_OK;
 }
 
@@ -248,12 +276,61 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     hipStream_t s = (hipStream_t)stream;
     const CamK cam = make_cam(camera);
     const BwdWs bw = carve_bwd(ws, N);
+    const int st = g_timer.bwd_step;
+    mark(st, 10, s);
     HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
-    if (D > 0) {
-        HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));
-        HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
-    }
+    if (D > 0) HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));
+    mark(st, 11, s);
+    if (D > 0) HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
+    mark(st, 12, s);
     HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));
+    mark(st, 13, s);
+    if (g_timer.on) ++g_timer.bwd_step;
+    return GSR_OK;
+}
+
+int gsr_stage_timing(int enable, int max_steps)
+{
+    if (g_timer.ev) {
+        for (size_t i = 0; i < (size_t)g_timer.max_steps * StageTimer::PER; ++i) (void)hipEventDestroy(g_timer.ev[i]);
+        free(g_timer.ev);
+        g_timer.ev = nullptr;
+    }
+    g_timer.on = false;
+    g_timer.max_steps = g_timer.fwd_step = g_timer.bwd_step = 0;
+    if (!enable) return GSR_OK;
+    if (max_steps <= 0 || max_steps > 4096) return GSR_E_DIMS;
+    g_timer.ev = (hipEvent_t *)calloc((size_t)max_steps * StageTimer::PER, sizeof(hipEvent_t));
+    if (!g_timer.ev) return GSR_E_WORKSPACE;
+    for (size_t i = 0; i < (size_t)max_steps * StageTimer::PER; ++i) HIP_TRY(hipEventCreate(&g_timer.ev[i]));
+    g_timer.max_steps = max_steps;
+    g_timer.on = true;
+    return GSR_OK;
+}
+
+int gsr_stage_times(float *avg_ms, int *steps)
+{
+    if (!avg_ms || !steps) return GSR_E_NULL;
+    for (int k = 0; k < GSR_NSTAGES; ++k) avg_ms[k] = 0.0f;
+    int n = g_timer.fwd_step < g_timer.bwd_step ? g_timer.fwd_step : g_timer.bwd_step;
+    if (n > g_timer.max_steps) n = g_timer.max_steps;
+    *steps = n;
+    if (!g_timer.on || n == 0) return GSR_OK;
+    // stage k of the forward lies between event slots k and k+1 (k = 0..8); backward stages 9..11 between 10+j and 11+j
+    for (int st = 0; st < n; ++st) {
+        for (int k = 0; k < 9; ++k) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, g_timer.at(st, k), g_timer.at(st, k + 1)));
+            avg_ms[k] += ms;
+        }
+        for (int j = 0; j < 3; ++j) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, g_timer.at(st, 10 + j), g_timer.at(st, 11 + j)));
+            avg_ms[9 + j] += ms;
+        }
+    }
+    for (int k = 0; k < GSR_NSTAGES; ++k) avg_ms[k] /= (float)n;
+    g_timer.fwd_step = g_timer.bwd_step = 0;
     return GSR_OK;
 }
 

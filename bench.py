@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""
+bench.py -- forward+backward Mpixels/s of the rasterizer on BASELINE.json's headline workload:
+synthetic 800x800, 1M Gaussians, SH degree 3 (config "C3").
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+
+A step = one render_gaussians() + one backward() of one camera view per GPU, all inputs already
+resident in HBM (device torch tensors), dL/dpixels fixed.  With N GPUs every rank holds the full
+(replicated) scene and renders its own view; the 59-float-per-Gaussian gradient arena is summed with
+ONE RCCL all-reduce per step and scaled by 1/N.  `value` = N * W * H / step time.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (longest average stage) measured with HIP events recorded by the
+                  library on the launch stream during the timed region, priced against the 8 TB/s HBM
+                  peak with the algorithmic bytes of DESIGN.md; `pipeline` = the same for the whole
+                  forward+backward byte budget B = 340 N + 596 Nv + 128 D + 16 Tn + 44 P;
+  cpu_baseline -- the CPU oracle (a single-thread C restatement of the reference kernels; Warp's CPU
+                  backend is also one serial loop) on the same scene and view, rank 0, N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def stage_bytes(N, Nv, D, P, Tn):
+    """Algorithmic HBM bytes per launch of each timed stage (DESIGN.md 'Kernels and rooflines')."""
+    return {
+        "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv + 80 * N,   # + 64 B record, 8 B rect, 8 B depth item
+        "scan": 8 * N,
+        "depth_sort": 4 * 24 * N,
+        "depth_scan": 16 * N,
+        "expand": 20 * Nv + 8 * D,
+        "tile_sort": 2 * 24 * D,
+        "ranges": 12 * D + 8 * Tn,
+        "blend_fwd": 68 * D + 8 * Tn + 24 * P,
+        "bwd_prep": 64 * N + 40 * N + 64 * N,
+        "blend_bwd": 68 * D + 8 * Tn + 20 * P + 36 * Nv,
+        "geom_bwd": 64 * N + 4 * N + 300 * Nv + 276 * N,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    gsr = importlib.import_module("3dgs-native_amd")
+    cfg = gsr.scenes.CONFIGS[args.config]
+    W, H, N = cfg["width"], cfg["height"], cfg["n"]
+    sc = gsr.scenes.synthetic_scene(N, cfg["scale_median"], cfg["scale_sigma"], cfg["seed"])  # same on every rank
+    pose = gsr.scenes.LEGO_FRAME0 if world == 1 else gsr.scenes.orbit_pose(rank, world)
+    cam = gsr.cameras.nerf_camera(pose, W, H, gsr.scenes.LEGO_CAMERA_ANGLE_X)
+    bg = np.zeros(3, np.float32)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    means, shs, opac, scales, rots = t(sc["means"]), t(sc["shs"]), t(sc["opacities"]), t(sc["scales"]), t(sc["rotations"])
+    dpix = t(np.random.default_rng(99).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3))
+    fkw = dict(background=bg, means3D=means, colors=None, opacity=opac, scales=scales, rotations=rots, scale_modifier=1.0,
+               viewmatrix=cam["world_to_camera"], projmatrix=cam["full_proj_matrix"], tan_fovx=cam["tan_fovx"],
+               tan_fovy=cam["tan_fovy"], image_height=H, image_width=W, sh=shs, degree=3, campos=cam["camera_center"],
+               prefiltered=False, antialiasing=False, clamped=True)
+
+    def step():
+        img, depth, buf = gsr.render_gaussians(**fkw)
+        grads = gsr.backward(
+            background=bg, means3D=means, dL_dpixels=dpix, opacity=opac, shs=shs, scales=scales, rotations=rots,
+            scale_modifier=1.0, viewmatrix=fkw["viewmatrix"], projmatrix=fkw["projmatrix"], tan_fovx=fkw["tan_fovx"],
+            tan_fovy=fkw["tan_fovy"], image_height=H, image_width=W, campos=fkw["campos"], radii=buf["radii"],
+            means2D=buf["points_xy_image"], conic_opacity=buf["conic_opacity"], rgb=buf["colors"], cov3Ds=buf["cov3Ds"],
+            clamped=buf["clamped_state"], geom_buffer=None, binning_buffer={"point_list": buf["point_list"]},
+            img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]}, degree=3)
+        if world > 1:
+            dist.all_reduce(grads["_arena"], op=dist.ReduceOp.SUM)
+            grads["_arena"].mul_(1.0 / world)
+        return buf, grads
+
+    for _ in range(args.warmup):
+        buf, grads = step()
+    torch.cuda.synchronize()
+    D = int(buf["point_list"].shape[0])
+    Nv = int((buf["radii"] > 0).sum().item())
+
+    use_events = not args.no_stage_events
+    if use_events:
+        gsr._lib.stage_timing(True, args.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stages, nrec = ({}, 0)
+    if use_events:
+        stages, nrec = gsr._lib.stage_times()
+        gsr._lib.stage_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * W * H / (elapsed / args.steps) / 1e6
+
+    out = {
+        "metric": "Mpixels/s forward+backward at 800x800, 1M Gaussians" if args.config == "C3" else f"Mpixels/s forward+backward ({args.config})",
+        "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: synthetic {W}x{H}, {N} Gaussians, SH degree 3, seed {cfg['seed']}, forward+backward, "
+                               f"Lego train pose 0" + (" rotated per rank" if world > 1 else ""),
+                   "width": W, "height": H, "gaussians": N, "visible": Nv, "tile_pairs_D": D, "views_per_step": world,
+                   "parallelism": f"dp{world}: one view per GPU, replicated Gaussians" + (", RCCL all-reduce of the 59-float gradient arena" if world > 1 else "")},
+    }
+
+    if rank == 0:
+        P, Tn = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        if stages and nrec > 0:
+            sb = stage_bytes(N, Nv, D, P, Tn)
+            timed = {k: v for k, v in stages.items() if k in sb}
+            dom = max(timed, key=timed.get)
+            dur_s = timed[dom] * 1e-3
+            achieved = sb[dom] / dur_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(args.config, {}).get(dom)
+            gpu_ms = sum(stages.values())
+            B = 340 * N + 596 * Nv + 128 * D + 16 * Tn + 44 * P
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "algorithmic_bytes": int(sb[dom]), "avg_ms": round(timed[dom], 4), "steps_measured": nrec,
+                               "pipeline": {"algorithmic_bytes": int(B), "gpu_ms": round(gpu_ms, 4),
+                                            "achieved": round(B / (gpu_ms * 1e-3) / 1e9, 2),
+                                            "frac": round(B / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                               "stage_ms": {k: round(v, 4) for k, v in stages.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            okw = dict(fkw)
+            for k_np, k_kw in [("means", "means3D"), ("opacities", "opacity"), ("scales", "scales"), ("rotations", "rotations"), ("shs", "sh")]:
+                okw[k_kw] = sc[k_np]
+            t0 = time.perf_counter()
+            oi, od, ob = oracle.render_gaussians(**okw)
+            t_f = time.perf_counter() - t0
+            geom = {"radii": ob["radii"], "means2D": ob["points_xy_image"], "conic_opacity": ob["conic_opacity"], "rgb": ob["colors"],
+                    "clamped_state": ob["clamped_state"]}
+            t0 = time.perf_counter()
+            oracle.backward(background=bg, means3D=sc["means"], dL_dpixels=dpix.cpu().numpy(), opacity=sc["opacities"], shs=sc["shs"],
+                            scales=sc["scales"], rotations=sc["rotations"], viewmatrix=fkw["viewmatrix"], projmatrix=fkw["projmatrix"],
+                            tan_fovx=fkw["tan_fovx"], tan_fovy=fkw["tan_fovy"], image_height=H, image_width=W, campos=fkw["campos"],
+                            cov3Ds=ob["cov3Ds"], geom_buffer=geom, binning_buffer={"point_list": ob["point_list"]},
+                            img_buffer={"ranges": ob["ranges"], "final_Ts": ob["final_Ts"], "n_contrib": ob["n_contrib"]})
+            t_b = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(W * H / (t_f + t_b) / 1e6, 5), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                                   "sample": f"one full {args.config} frame (same scene and view), forward {t_f:.2f} s + backward {t_b:.2f} s, "
+                                             f"single-thread C oracle (gcc -O2), host has {os.cpu_count()} cores"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,29 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
                  const GsrBinning *binning, const GsrImage *image, const float *dL_dpixels,
                  const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- profiling aid (the only process-wide state in the library; not thread-safe) ----------------
+ * With timing enabled every stage boundary of the three entry points records a hipEvent on the
+ * caller's stream (about 1 us each); up to `max_steps` forward+backward pairs are kept.
+ * gsr_stage_times() -- call it after synchronising the stream -- returns the average milliseconds per
+ * stage over the steps recorded since enabling, and clears the record. */
+enum {
+    GSR_ST_PREPROCESS = 0, /* preprocess_kernel */
+    GSR_ST_SCAN,           /* id-order scan of tiles_touched (3 kernels) */
+    GSR_ST_COUNT_SYNC,     /* D readback */
+    GSR_ST_DEPTH_SORT,     /* 4 radix passes over N items */
+    GSR_ST_DEPTH_SCAN,     /* depth-order offsets */
+    GSR_ST_EXPAND,         /* (tile,id) item expansion */
+    GSR_ST_TILE_SORT,      /* radix passes over D items */
+    GSR_ST_RANGES,         /* point_list + ranges */
+    GSR_ST_BLEND_FWD,      /* blend_forward_kernel */
+    GSR_ST_BWD_PREP,       /* accumulator memset + record packing */
+    GSR_ST_BLEND_BWD,      /* blend_backward_kernel */
+    GSR_ST_GEOM_BWD,       /* geom_backward_kernel */
+    GSR_NSTAGES
+};
+int gsr_stage_timing(int enable, int max_steps);
+int gsr_stage_times(float *avg_ms /* [GSR_NSTAGES] host */, int *steps /* host */);
+
 #ifdef __cplusplus
 }
 #endif
