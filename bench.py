@@ -102,8 +102,7 @@ def main():
             clamped=buf["clamped_state"], geom_buffer=None, binning_buffer={"point_list": buf["point_list"]},
             img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]}, degree=3)
         if world > 1:
-            dist.all_reduce(grads["_arena"], op=dist.ReduceOp.SUM)
-            grads["_arena"].mul_(1.0 / world)
+            gsr.dist.reduce_gradients(grads["_arena"], world)
         return buf, grads
 
     for _ in range(args.warmup):

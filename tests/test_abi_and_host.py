@@ -1,0 +1,112 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gsr.h declares (no compute
+calls without a GPU), ctypes struct layouts match the header, host-side camera math follows the
+reference's conventions, error codes map to the reference's exception types."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, PKG_NAME, lego_camera, sub
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    path = os.path.join(ROOT, PKG_NAME, "libgsr_hip.so")
+    if not os.path.exists(path):   # hipcc cross-compiles gfx950 without a GPU
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, PKG_NAME, "csrc")])
+    return path
+
+
+def test_every_declared_symbol_is_exported(libpath):
+    hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    declared = set(re.findall(r"\b(gsr_[a-z_]+)\s*\(", hdr))
+    assert {"gsr_forward_count", "gsr_forward_render", "gsr_backward", "gsr_strerror"} <= declared
+    lib = C.CDLL(libpath)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in gsr.h but not exported"
+    _lib = sub("_lib")
+    assert set(_lib.EXPORTS) == declared, "ctypes binding and header disagree"
+
+
+def test_host_only_entry_points(libpath):
+    _lib = sub("_lib")
+    L = _lib.lib()
+    assert L.gsr_abi_version() == 1
+    assert _lib.strerror(0) == "ok" and "2^30" in _lib.strerror(_lib.GSR_E_OVERFLOW)
+    a, b = L.gsr_geom_workspace_bytes(1000), L.gsr_geom_workspace_bytes(2000)
+    assert 0 < a < b and b >= 2000 * (64 + 8 + 8)
+    assert L.gsr_binning_workspace_bytes(1000, 5000, 800, 800) >= 2 * 5000 * 8
+    assert L.gsr_backward_workspace_bytes(1000, 5000, 800, 800) >= 1000 * 128
+    with pytest.raises(ValueError):
+        _lib.check(_lib.GSR_E_OVERFLOW)       # reference raises ValueError (forward.py:765-767)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.GSR_E_WORKSPACE)
+
+
+def test_struct_layouts_match_header():
+    _lib = sub("_lib")
+    assert C.sizeof(_lib.GsrCamera) == (16 + 16 + 3 + 3 + 2 + 2) * 4 + 2 * 4
+    assert C.sizeof(_lib.GsrScene) == 8 + 5 * 8 + 3 * 4 + 4   # trailing pad to 8
+    assert C.sizeof(_lib.GsrGeom) == 9 * 8 and C.sizeof(_lib.GsrGrads) == 8 * 8
+    assert C.sizeof(_lib.GsrBinning) == 24 and C.sizeof(_lib.GsrImage) == 32
+    assert _lib.GsrCamera.focal_x.offset == (16 + 16 + 3 + 3 + 2) * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    _lib = sub("_lib")
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgsr_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg_dir = os.path.join(ROOT, PKG_NAME)
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "gsro_" not in text, f
+
+
+def test_nerf_camera_conventions(cameras):
+    cam = lego_camera(cameras, 0, 800, 800)
+    w2c = cam["world_to_camera"]
+    assert w2c.dtype == np.float32
+    np.testing.assert_allclose(w2c[:3, 3], 0.0, atol=1e-7)            # row-vector form: translation in row 3
+    assert abs(w2c[3, 3] - 1.0) < 1e-7 and np.abs(w2c[3, :3]).max() > 1.0
+    R = w2c[:3, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-5)
+    # camera centre maps to the view-space origin
+    c = np.append(cam["camera_center"], 1.0) @ w2c
+    np.testing.assert_allclose(c[:3], 0.0, atol=1e-5)
+    # full projection = view @ proj, tan_fov from camera_angle_x
+    np.testing.assert_allclose(cam["full_proj_matrix"], w2c @ cam["proj_matrix"], rtol=1e-6)
+    assert abs(cam["tan_fovx"] - np.tan(0.5 * 0.6911112070083618)) < 1e-9
+    # a point 4 units in front of the camera projects to the image centre with w = depth
+    p_world = np.append(cam["camera_center"], 1.0) + np.append(4.0 * np.linalg.inv(w2c)[2, :3], 0.0)
+    hom = p_world @ cam["full_proj_matrix"]
+    np.testing.assert_allclose(hom[:2] / hom[3], 0.0, atol=1e-5)
+    assert abs(hom[3] - 4.0) < 1e-4
+
+
+def test_toy_camera_quirk_q3(cameras):
+    cam = cameras.toy_camera()
+    v = cam["view_matrix"]
+    # render.py passes the un-transposed matrix: translation sits in COLUMN 3, so p*V has no translation
+    np.testing.assert_allclose(v[:3, 3], [0, 0, 5])
+    np.testing.assert_allclose(v[3, :3], 0.0)
+    assert abs(cam["tan_fovx"] - 0.5578517) < 1e-6
+    np.testing.assert_allclose(cam["camera_center"], [0, 0, 5], atol=1e-6)   # 'camera_center = (0,0,5)' SURVEY section 4
+
+
+def test_synthetic_scene_is_seeded(scenes):
+    a, b = scenes.synthetic_scene(100, 0.02, 0.5, 7), scenes.synthetic_scene(100, 0.02, 0.5, 7)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert a["shs"].shape == (100, 16, 3) and a["rotations"].shape == (100, 4)
+    np.testing.assert_allclose(np.linalg.norm(a["rotations"], axis=1), 1.0, atol=1e-6)
+    assert a["scales"].min() >= 1e-3

@@ -1,0 +1,54 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the gradient-arena reduction and the view sharding."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG_NAME
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import importlib
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    d = importlib.import_module(f"{PKG_NAME}.dist")
+    r, w = d.init_from_env(backend="gloo")
+    n = 1000
+    arena = torch.full((d.ARENA_FLOATS * n,), float(rank + 1))
+    arena[:3] = torch.tensor([1.0, 2.0, 3.0]) * (rank + 1)
+    d.reduce_gradients(arena, w, average=True)
+    views = d.views_for_rank(8, r, w)
+    parts = d.arena_views(arena, n)
+    q.put((r, w, arena[:4].tolist(), float(arena[-1]), views, {k: tuple(v.shape) for k, v in parts.items()}))
+    torch.distributed.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, w, head, tail, views, shapes in res:
+        assert w == 2
+        np.testing.assert_allclose(head, [1.5, 3.0, 4.5, 1.5])    # mean of rank+1 scalings
+        assert tail == 1.5
+        assert shapes == {"dL_dmean3D": (1000, 3), "dL_dscale": (1000, 3), "dL_drot": (1000, 4), "dL_dopacity": (1000,),
+                          "dL_dshs": (16000, 3)}
+    assert res[0][4] == [0, 2, 4, 6] and res[1][4] == [1, 3, 5, 7]
