@@ -6,8 +6,6 @@
 
 #include "gsr_internal.h"
 
-extern int gsr_blend_p_override;
-
 namespace {
 
 #define HIP_TRY(expr)                                                                                                         \
@@ -133,6 +131,9 @@ void read_tuning()
     if (done) return;
     done = true;
     if (const char *e = getenv("GSR_BLEND_P")) gsr_blend_p_override = atoi(e);
+    if (const char *e = getenv("GSR_BWD_P")) gsr_bwd_p_override = atoi(e);
+    if (const char *e = getenv("GSR_BWD_MODE")) gsr_bwd_mode = atoi(e);
+    if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e);
 }
 
 } // namespace
@@ -281,7 +282,10 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
     if (D > 0) HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));
     mark(st, 11, s);
-    if (D > 0) HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
+    if (D > 0) {
+        if (gsr_bwd_mode == 1) HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
+        else HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
+    }
     mark(st, 12, s);
     HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));
     mark(st, 13, s);

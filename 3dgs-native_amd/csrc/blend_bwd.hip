@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float *__restri
 
 } // namespace
 
-extern int gsr_blend_p_override;
+int gsr_bwd_p_override = 4;
+int gsr_bwd_mode = 0;
 
 hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s)
 {
@@ -236,8 +237,8 @@ hipError_t gsr_launch_blend_backward(const CamK &cam, const int32_t *ranges, con
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-    int P = gsr_blend_p_override;
-    if (P != 1 && P != 2 && P != 4) P = 1;
+    int P = gsr_bwd_p_override;
+    if (P != 1 && P != 2 && P != 4) P = 4;
 #define LAUNCH(PP)                                                                                                            \
     hipLaunchKernelGGL(blend_backward_kernel<PP>, dim3(tiles), dim3(256 / PP), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0],     \
                        cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels, acc)

@@ -1,0 +1,270 @@
+// blend_bwd_splat.hip -- Gaussian-parallel gradient replay for gfx950 (default backward blend).
+//
+// Same mathematics as the reference's wp_render_backward_kernel (backward.py:559-706), parallelised
+// the other way round.  The reference (and blend_bwd.hip) gives a lane a PIXEL and walks the list, so
+// every (pixel, entry) pair produces nine values that must be summed over pixels.  Here a lane owns a
+// list ENTRY and the wave walks the pixels, so the nine gradients of an entry accumulate in that
+// lane's registers with no cross-lane reduction at all; what crosses lanes instead is the per-pixel
+// recurrence over entries, and that is two wave-wide DPP scans per pixel:
+//     P_k = prod_{deeper j <= k} (1 - alpha_j)        ->  T_k = T_final / P_k          (backward.py:658)
+//     Q_k = sum_{deeper j <  k} alpha_j T_j (c_j . dL_dpixel)  ( = T_k (1-alpha_k) accum_rec . dL_dpixel, :667-671)
+// so that dL_dalpha_k = T_k (c_k . dL_dpixel) - (Q_k + T_final bg . dL_dpixel) / (1 - alpha_k)   (:671-680).
+// One single-wave workgroup per 8x8 pixel block (4 per tile, 10 000 at 800x800) replays its tile's
+// list back to front.  Most entries of a tile's list cannot touch a given 8x8 block, so the wave first
+// COMPACTS the stream: 64 candidates at a time are tested against the block rectangle (exact convex
+// minimum of the conic over the rectangle vs ln(255 o), conservative) and survivors are queued in an
+// LDS ring in order; each full bucket of 64 survivors (lane 0 = deepest) then runs the pixel loop, so
+// lanes are mostly live.  Per-pixel carries (P, Q) live in LDS between buckets; pixels whose n_contrib
+// ends before the bucket are skipped wave-uniformly.
+// After a bucket each lane holds the block's complete gradient for its entry; an LDS transpose lets 16
+// lanes write one 64-byte GradRec with float atomics (4 whole 64-B requests per wave instruction).
+//
+// Differences from the reference in float rounding only: sums over pixels/entries are re-associated
+// (quirk Q15) and 1/x uses v_rcp_f32 (1 ulp).
+#include "gsr_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v, float identity)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// inclusive scans over the 64 lanes (lane 0 first)
+__device__ __forceinline__ float wave_scan_mul(float v)
+{
+    v *= dpp_get<0x111, 0xF>(v, 1.0f); // row_shr:1
+    v *= dpp_get<0x112, 0xF>(v, 1.0f); // row_shr:2
+    v *= dpp_get<0x114, 0xF>(v, 1.0f); // row_shr:4
+    v *= dpp_get<0x118, 0xF>(v, 1.0f); // row_shr:8
+    v *= dpp_get<0x142, 0xA>(v, 1.0f); // row_bcast:15 -> rows 1,3
+    v *= dpp_get<0x143, 0xC>(v, 1.0f); // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v)
+{
+    v += dpp_get<0x111, 0xF>(v, 0.0f);
+    v += dpp_get<0x112, 0xF>(v, 0.0f);
+    v += dpp_get<0x114, 0xF>(v, 0.0f);
+    v += dpp_get<0x118, 0xF>(v, 0.0f);
+    v += dpp_get<0x142, 0xA>(v, 0.0f);
+    v += dpp_get<0x143, 0xC>(v, 0.0f);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// Conservative test: can the Gaussian reach alpha >= 1/255 anywhere in the pixel rectangle
+// [x0,x0+7] x [y0,y0+7]?  alpha = o*exp(power) >= 1/255  <=>  q(d) = 0.5(a dx^2 + c dy^2) + b dx dy <= ln(255 o).
+// q is a convex quadratic (the conic is the inverse of a positive-definite covariance), so its minimum
+// over the rectangle is 0 if the centre is inside, else it lies on one of the four edges, where it is a
+// clamped 1-D quadratic.  A small slack keeps the test a strict superset of the exact per-pixel test.
+__device__ __forceinline__ float edge_min_q(float qa, float qb, float qc, float u, float vlo, float vhi)
+{
+    // minimise 0.5*qa*u^2 + 0.5*qc*v^2 + qb*u*v over v in [vlo, vhi]
+    float v = -qb * u * fast_rcp(qc);
+    v = fminf(vhi, fmaxf(vlo, v));
+    return 0.5f * (qa * u * u + qc * v * v) + qb * u * v;
+}
+__device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float opacity, float x0, float y0)
+{
+    if (!(opacity * 255.0f >= 1.0f)) return false;
+    const float tau = __logf(opacity * 255.0f); // >= 0
+    // d = g - pixel, pixel in [x0, x0+7] -> d in [gx-x0-7, gx-x0]
+    const float dxl = gx - (x0 + 7.0f), dxh = gx - x0, dyl = gy - (y0 + 7.0f), dyh = gy - y0;
+    float qmin;
+    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) qmin = 0.0f;
+    else {
+        qmin = edge_min_q(ca, cb, cc, dxl, dyl, dyh);
+        qmin = fminf(qmin, edge_min_q(ca, cb, cc, dxh, dyl, dyh));
+        qmin = fminf(qmin, edge_min_q(cc, cb, ca, dyl, dxl, dxh));
+        qmin = fminf(qmin, edge_min_q(cc, cb, ca, dyh, dxl, dxh));
+    }
+    return qmin <= tau * 1.0001f + 1e-3f;
+}
+
+constexpr int QCAP = 128; // ring of compacted entries (power of two, >= 2*64 - 1)
+
+__global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
+                                                                  const int32_t *__restrict__ ranges,
+                                                                  const int32_t *__restrict__ point_list,
+                                                                  const BlendRec *__restrict__ rec,
+                                                                  const float *__restrict__ final_T,
+                                                                  const int32_t *__restrict__ n_contrib,
+                                                                  const float *__restrict__ dL_dpixels, GradRec *__restrict__ acc, int dbg)
+{
+    __shared__ float4 s_pa[64];     // px, py, Tfin, bgdot*Tfin
+    __shared__ float4 s_pb[64];     // dpix r,g,b, kept (as int bits)
+    __shared__ float2 s_carry[64];  // P (product of deeper (1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
+    __shared__ float4 s_qa[QCAP];   // ring: xy.x xy.y con.a con.b
+    __shared__ float4 s_qb[QCAP];   //       con.c opacity r g
+    __shared__ float2 s_qc[QCAP];   //       b, list index (int bits)
+    __shared__ int s_qid[QCAP];
+    __shared__ float s_g[64][13];   // per-entry gradients for the transposed flush (odd stride: no bank conflicts)
+    __shared__ int s_id[64];
+
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
+    const int start = range.x, end = range.y;
+    if (end <= start) return;
+
+    // lane q prepares the constants of pixel q of the block
+    const int bx0 = tile_x * 16 + (sub & 1) * 8, by0 = tile_y * 16 + (sub >> 1) * 8;
+    const int my_x = bx0 + (lane & 7), my_y = by0 + (lane >> 3);
+    int kept = start;
+    {
+        float Tfin = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+        if (my_x < W && my_y < H) {
+            const size_t px = (size_t)my_y * W + my_x;
+            Tfin = final_T[px];
+            kept = min(end, start + n_contrib[px]);
+            d0 = dL_dpixels[3 * px]; d1 = dL_dpixels[3 * px + 1]; d2 = dL_dpixels[3 * px + 2];
+        }
+        float bgdot = bg0 * d0;
+        bgdot += bg1 * d1;
+        bgdot += bg2 * d2;
+        s_pa[lane] = make_float4((float)my_x, (float)my_y, Tfin, Tfin * bgdot);
+        s_pb[lane] = make_float4(d0, d1, d2, __int_as_float(kept));
+        s_carry[lane] = make_float2(1.0f, 0.0f);
+    }
+    const int hi_all = wave_max_i(kept);
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const float fx0 = (float)bx0, fy0 = (float)by0;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    __syncthreads();
+
+    int cursor = hi_all; // next list index (exclusive) to pull candidates from, moving towards `start`
+    int head = 0, qn = 0; // ring state (wave-uniform)
+    for (;;) {
+        // ---- fill: pull candidates (deepest first) until a full bucket is queued or the list is exhausted ----
+        while (qn < 64 && cursor > start) {
+            const int lo = max(start, cursor - 64);
+            const int idx = cursor - 1 - lane;
+            bool hit = false;
+            int id = 0;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            float colb = 0.0f;
+            if (idx >= lo) {
+                id = point_list[idx];
+                const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
+                a = rp[0];
+                b = rp[1];
+                colb = rp[2].x;
+                hit = block_may_hit(a.x, a.y, a.z, a.w, b.x, b.y, fx0, fy0);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int slot = (head + qn + __popcll(m & lt_mask)) & (QCAP - 1);
+                s_qa[slot] = a;
+                s_qb[slot] = b;
+                s_qc[slot] = make_float2(colb, __int_as_float(idx));
+                s_qid[slot] = id;
+            }
+            qn += __popcll(m);
+            cursor = lo;
+        }
+        if (qn == 0) break;
+        __syncthreads();
+
+        // ---- one bucket: lane k takes the k-th queued entry (still deepest first) ----
+        const int n = min(64, qn);
+        const bool valid = lane < n;
+        const int slot = (head + lane) & (QCAP - 1);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float colb = 0.0f;
+        int idx = 0x7FFFFFFF, id = 0;
+        if (valid) {
+            a = s_qa[slot];
+            b = s_qb[slot];
+            const float2 c = s_qc[slot];
+            colb = c.x;
+            idx = __float_as_int(c.y);
+            id = s_qid[slot];
+        }
+        const int idx_min = __shfl(idx, n - 1, 64); // shallowest entry of the bucket
+        head = (head + n) & (QCAP - 1);
+        qn -= n;
+
+        float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
+        bool touched = false;
+
+        for (int q = 0; q < ((dbg & 2) ? 1 : 64); ++q) {
+            const float4 pb = s_pb[q];
+            const int pkept = __float_as_int(pb.w);
+            if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
+            const float4 pa = s_pa[q];
+            const float2 carry = s_carry[q];
+            const float d_x = a.x - pa.x, d_y = a.y - pa.y;
+            const float power = -0.5f * (a.z * d_x * d_x + b.x * d_y * d_y) - a.w * d_x * d_y;
+            const float G = fast_exp(power);
+            const float alpha = fminf(0.99f, b.y * G);
+            const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
+            const float one_m = 1.0f - alpha;
+            const float m = live ? one_m : 1.0f;
+            const float Pi = wave_scan_mul(m);
+            const float denom = carry.x * Pi;           // product of (1-alpha) over this entry and everything deeper
+            const float T = pa.z * fast_rcp(denom);     // transmittance in front of this entry
+            float cd = b.z * pb.x;
+            cd += b.w * pb.y;
+            cd += colb * pb.z;
+            const float w = alpha * T;
+            const float qv = live ? w * cd : 0.0f;
+            const float Qi = wave_scan_add(qv);
+            const float Qe = carry.y + (Qi - qv);       // deeper entries only
+            if (lane == 63) s_carry[q] = make_float2(denom, carry.y + Qi);
+            if (live) {
+                touched = true;
+                const float inv = fast_rcp(one_m);
+                const float dL_dalpha = T * cd - (Qe + pa.w) * inv;
+                g_c0 += w * pb.x; g_c1 += w * pb.y; g_c2 += w * pb.z;
+                const float dL_dG = b.y * dL_dalpha;
+                const float gdx = G * d_x, gdy = G * d_y;
+                const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                const float dG_ddely = -gdy * b.x - gdx * a.w;
+                g_mx += dL_dG * dG_ddelx * ddelx_dx;
+                g_my += dL_dG * dG_ddely * ddely_dy;
+                g_ca += -0.5f * gdx * d_x * dL_dG;
+                g_cb += -0.5f * gdx * d_y * dL_dG;
+                g_cc += -0.5f * gdy * d_y * dL_dG;
+                g_op += G * dL_dalpha;
+            }
+        }
+
+        // transpose through LDS: 16 lanes per entry -> one 64-byte accumulator record each
+        s_id[lane] = touched ? id : -1;
+        s_g[lane][0] = g_c0; s_g[lane][1] = g_c1; s_g[lane][2] = g_c2; s_g[lane][3] = g_mx; s_g[lane][4] = g_my;
+        s_g[lane][5] = g_ca; s_g[lane][6] = g_cb; s_g[lane][7] = g_cc; s_g[lane][8] = g_op;
+        __syncthreads();
+        const int c = lane & 15;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int e = r * 4 + (lane >> 4);
+            const int eid = s_id[e];
+            if (c < 9 && eid >= 0 && !(dbg & 1)) unsafeAtomicAdd(&acc[eid].f[c], s_g[e][c]);
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+int gsr_debug_flags = 0; // GSR_DEBUG: bit0 = skip atomics, bit1 = one pixel per bucket (timing ablations only)
+
+hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
+                                           const GsrImage &img, const float *dL_dpixels, GradRec *acc, hipStream_t s)
+{
+    const int tiles = cam.grid_x * cam.grid_y;
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(blend_backward_splat_kernel, dim3(tiles * 4), dim3(64), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1],
+                       cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels, acc, gsr_debug_flags);
+    return hipGetLastError();
+}

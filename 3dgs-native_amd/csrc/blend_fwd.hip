@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256 / P) void blend_forward_kernel(int W, int H, in
 
 } // namespace
 
-int gsr_blend_p_override = 0; // test/tuning hook: force P (set through GSR_BLEND_P in api.hip)
+int gsr_blend_p_override = 1; // pixels per lane (GSR_BLEND_P)
 
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
                                     const GsrImage &img, hipStream_t s)

@@ -71,5 +71,14 @@ hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, h
 hipError_t gsr_launch_blend_backward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                      const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
                                      GradRec *acc, hipStream_t s);
+hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
+                                           const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
+                                           GradRec *acc, hipStream_t s);
 hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc,
                                     const GsrGrads &gr, hipStream_t s);
+
+// tuning knobs (read once from the environment by api.hip; defaults are the measured best)
+extern int gsr_blend_p_override;   // GSR_BLEND_P  : pixels per lane in blend_forward_kernel (1, 2, 4)
+extern int gsr_bwd_p_override;     // GSR_BWD_P    : pixels per lane in the pixel-parallel backward
+extern int gsr_bwd_mode;           // GSR_BWD_MODE : 0 = Gaussian-parallel backward (default), 1 = pixel-parallel
+extern int gsr_debug_flags;        // GSR_DEBUG    : timing ablations (wrong results), never set in production
