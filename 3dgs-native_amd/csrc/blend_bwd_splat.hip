@@ -34,24 +34,32 @@ __device__ __forceinline__ float dpp_get(float v, float identity)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
 // inclusive scans over the 64 lanes (lane 0 first)
+// One fused v_mul_f32_dpp per step: lanes whose DPP source is out of the row (or whose row is masked)
+// are write-disabled and keep v, which is exactly "multiply by 1".  hipcc emits v_mov + v_mov_dpp +
+// v_mul for the builtin form.  A VALU write followed by a DPP read of the same VGPR needs 2 wait
+// states; the s_nop is inside the asm because hipcc does not pad around inline asm.
 __device__ __forceinline__ float wave_scan_mul(float v)
 {
-    v *= dpp_get<0x111, 0xF>(v, 1.0f); // row_shr:1
-    v *= dpp_get<0x112, 0xF>(v, 1.0f); // row_shr:2
-    v *= dpp_get<0x114, 0xF>(v, 1.0f); // row_shr:4
-    v *= dpp_get<0x118, 0xF>(v, 1.0f); // row_shr:8
-    v *= dpp_get<0x142, 0xA>(v, 1.0f); // row_bcast:15 -> rows 1,3
-    v *= dpp_get<0x143, 0xC>(v, 1.0f); // row_bcast:31 -> rows 2,3
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float wave_scan_add(float v)
 {
-    v += dpp_get<0x111, 0xF>(v, 0.0f);
-    v += dpp_get<0x112, 0xF>(v, 0.0f);
-    v += dpp_get<0x114, 0xF>(v, 0.0f);
-    v += dpp_get<0x118, 0xF>(v, 0.0f);
-    v += dpp_get<0x142, 0xA>(v, 0.0f);
-    v += dpp_get<0x143, 0xC>(v, 0.0f);
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int wave_max_i(int v)
@@ -103,11 +111,8 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     __shared__ float4 s_pa[64];     // px, py, Tfin, bgdot*Tfin
     __shared__ float4 s_pb[64];     // dpix r,g,b, kept (as int bits)
     __shared__ float2 s_carry[64];  // P (product of deeper (1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
-    __shared__ float4 s_qa[QCAP];   // ring: xy.x xy.y con.a con.b
-    __shared__ float4 s_qb[QCAP];   //       con.c opacity r g
-    __shared__ float2 s_qc[QCAP];   //       b, list index (int bits)
-    __shared__ int s_qid[QCAP];
-    __shared__ float s_g[64][13];   // per-entry gradients for the transposed flush (odd stride: no bank conflicts)
+    __shared__ int2 s_ring[QCAP];   // compacted survivors: (Gaussian id, list index); records are re-gathered (L2 hits)
+    __shared__ float s_g[64][9];    // per-entry gradients for the transposed flush (odd stride: no bank conflicts)
     __shared__ int s_id[64];
 
     const int lane = threadIdx.x;
@@ -151,24 +156,14 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const int idx = cursor - 1 - lane;
             bool hit = false;
             int id = 0;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            float colb = 0.0f;
             if (idx >= lo) {
                 id = point_list[idx];
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
-                a = rp[0];
-                b = rp[1];
-                colb = rp[2].x;
+                const float4 a = rp[0], b = rp[1];
                 hit = block_may_hit(a.x, a.y, a.z, a.w, b.x, b.y, fx0, fy0);
             }
             const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int slot = (head + qn + __popcll(m & lt_mask)) & (QCAP - 1);
-                s_qa[slot] = a;
-                s_qb[slot] = b;
-                s_qc[slot] = make_float2(colb, __int_as_float(idx));
-                s_qid[slot] = id;
-            }
+            if (hit) s_ring[(head + qn + __popcll(m & lt_mask)) & (QCAP - 1)] = make_int2(id, idx);
             qn += __popcll(m);
             cursor = lo;
         }
@@ -183,12 +178,13 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         float colb = 0.0f;
         int idx = 0x7FFFFFFF, id = 0;
         if (valid) {
-            a = s_qa[slot];
-            b = s_qb[slot];
-            const float2 c = s_qc[slot];
-            colb = c.x;
-            idx = __float_as_int(c.y);
-            id = s_qid[slot];
+            const int2 e = s_ring[slot];
+            id = e.x;
+            idx = e.y;
+            const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
+            a = rp[0]; // xy.x xy.y con.a con.b
+            b = rp[1]; // con.c opacity r g
+            colb = rp[2].x;
         }
         const int idx_min = __shfl(idx, n - 1, 64); // shallowest entry of the bucket
         head = (head + n) & (QCAP - 1);
