@@ -16,6 +16,7 @@
 // the 1-2(y^2+z^2) matrix), Q3 ((dL_dt,1) * view^T adds view[j][3]), and Q16: backward() never passes
 // its scale_modifier down (backward.py:1155-1182; default 1.0 at :805), so the cov3d part runs with 1.0.
 #include "gsr_internal.h"
+#include "sh_stage.h"
 
 namespace {
 
@@ -60,8 +61,20 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dscale, float *__restrict__ dL_drot, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dshs, float *__restrict__ dL_dcolor, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N) return;
+    // SH rows (input coefficients, then in place the output gradients) live in LDS; moved cooperatively
+    __shared__ float4 s_rows[4 * SH_WAVE_F4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
+    const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
+    float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
+    if (rows_valid > 0 && degree > 0)
+        sh_rows_load(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, lds_wave, lane, rows_valid);
+    __syncthreads();
+    float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
+
+    const int64_t idx = wave_row0 + lane;
+    const bool in_range = idx < N;
+    if (in_range) {
 
     const float4 *ap = reinterpret_cast<const float4 *>(acc + idx);
     const float4 a0 = ap[0], a1 = ap[1];
@@ -76,9 +89,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     dL_dopacity[idx] = a8;
 
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
-    float o_sh[48];
-#pragma unroll
-    for (int k = 0; k < 48; ++k) o_sh[k] = 0.0f;
+    int sh_written = 0; // number of leading SH coefficients whose gradient was written into the LDS row
 
     if (radii[idx] > 0) {
         const float mean[3] = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
@@ -181,50 +192,42 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                 float dRGB[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) dRGB[c] = g_col[c] * (1.0f + (-1.0f * clamped_state[3 * idx + c]));
-                float sh[48];
-                const float4 *shp = reinterpret_cast<const float4 *>(shs + (size_t)idx * 48);
-                const int nload = degree == 0 ? 0 : (degree == 1 ? 3 : (degree == 2 ? 7 : 12));
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < nload) v = shp[k];
-                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
-                }
                 const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
                 float dx_[3] = {0.f, 0.f, 0.f}, dy_[3] = {0.f, 0.f, 0.f}, dz_[3] = {0.f, 0.f, 0.f};
-#define SHV(k, c) sh[(k) * 3 + (c)]
+                // in-place: every read of coefficient k (SHV) happens before its slot is overwritten (OUT)
+#define SHV(k, c) row[(k) * 3 + (c)]
 #define OUT(k, coef)                                                                                                           \
     {                                                                                                                         \
         const float cf = (coef);                                                                                              \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c) o_sh[(k) * 3 + c] = cf * dRGB[c];                                        \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) row[(k) * 3 + c] = cf * dRGB[c];                                         \
     }
                 OUT(0, SH_C0);
+                sh_written = 1;
                 if (degree > 0) {
-                    OUT(1, -SH_C1 * y); OUT(2, SH_C1 * z); OUT(3, -SH_C1 * x);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         dx_[c] = -SH_C1 * SHV(3, c);
                         dy_[c] = -SH_C1 * SHV(1, c);
                         dz_[c] = SH_C1 * SHV(2, c);
                     }
+                    OUT(1, -SH_C1 * y); OUT(2, SH_C1 * z); OUT(3, -SH_C1 * x);
+                    sh_written = 4;
                     if (degree > 1) {
                         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                         const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
                                     C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
-                        OUT(4, C2_0 * xy); OUT(5, C2_1 * yz); OUT(6, C2_2 * (2.0f * zz - xx - yy)); OUT(7, C2_3 * xz); OUT(8, C2_4 * (xx - yy));
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             dx_[c] += C2_0 * y * SHV(4, c) + C2_2 * 2.0f * -x * SHV(6, c) + C2_3 * z * SHV(7, c) + C2_4 * 2.0f * x * SHV(8, c);
                             dy_[c] += C2_0 * x * SHV(4, c) + C2_1 * z * SHV(5, c) + C2_2 * 2.0f * -y * SHV(6, c) + C2_4 * 2.0f * -y * SHV(8, c);
                             dz_[c] += C2_1 * y * SHV(5, c) + C2_2 * 2.0f * 2.0f * z * SHV(6, c) + C2_3 * x * SHV(7, c);
                         }
+                        OUT(4, C2_0 * xy); OUT(5, C2_1 * yz); OUT(6, C2_2 * (2.0f * zz - xx - yy)); OUT(7, C2_3 * xz); OUT(8, C2_4 * (xx - yy));
+                        sh_written = 9;
                         if (degree > 2) {
                             const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
                                         C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
                                         C3_6 = -0.5900435899266435f;
-                            OUT(9, C3_0 * y * (3.0f * xx - yy)); OUT(10, C3_1 * xy * z); OUT(11, C3_2 * y * (4.0f * zz - xx - yy));
-                            OUT(12, C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)); OUT(13, C3_4 * x * (4.0f * zz - xx - yy));
-                            OUT(14, C3_5 * z * (xx - yy)); OUT(15, C3_6 * x * (xx - 3.0f * yy));
 #pragma unroll
                             for (int c = 0; c < 3; ++c) {
                                 dx_[c] += (C3_0 * SHV(9, c) * 3.0f * 2.0f * xy + C3_1 * SHV(10, c) * yz + C3_2 * SHV(11, c) * -2.0f * xy +
@@ -237,6 +240,10 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                                            C3_3 * SHV(12, c) * 3.0f * (2.0f * zz - xx - yy) + C3_4 * SHV(13, c) * 4.0f * 2.0f * xz +
                                            C3_5 * SHV(14, c) * (xx - yy));
                             }
+                            OUT(9, C3_0 * y * (3.0f * xx - yy)); OUT(10, C3_1 * xy * z); OUT(11, C3_2 * y * (4.0f * zz - xx - yy));
+                            OUT(12, C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)); OUT(13, C3_4 * x * (4.0f * zz - xx - yy));
+                            OUT(14, C3_5 * z * (xx - yy)); OUT(15, C3_6 * x * (xx - 3.0f * yy));
+                            sh_written = 16;
                         }
                     }
                 }
@@ -292,9 +299,11 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) { dL_dmean3D[3 * idx + k] = o_mean[k]; dL_dscale[3 * idx + k] = o_scale[k]; }
     *reinterpret_cast<float4 *>(dL_drot + 4 * idx) = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
-    float4 *op = reinterpret_cast<float4 *>(dL_dshs + (size_t)idx * 48);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) op[k] = make_float4(o_sh[4 * k], o_sh[4 * k + 1], o_sh[4 * k + 2], o_sh[4 * k + 3]);
+    // coefficients that got no gradient (culled Gaussian, lower degree) are zero, as in the reference's zero-initialised array
+    for (int k = sh_written * 3; k < 48; ++k) row[k] = 0.0f;
+    } // in_range
+    __syncthreads();
+    if (rows_valid > 0) sh_rows_store(reinterpret_cast<float4 *>(dL_dshs) + wave_row0 * 12, lds_wave, lane, rows_valid);
 }
 
 } // namespace

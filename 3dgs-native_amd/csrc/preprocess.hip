@@ -11,6 +11,7 @@
 // One thread per Gaussian, 256 per workgroup; every output is written for every i (zeros for culled
 // Gaussians, quirk Q11), so no buffer needs pre-zeroing.
 #include "gsr_internal.h"
+#include "sh_stage.h"
 
 namespace {
 
@@ -65,15 +66,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
     uint64_t *__restrict__ depth_item)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
+    __shared__ float4 s_rows[4 * SH_WAVE_F4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
+    const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
+    float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
+    if (rows_valid > 0) sh_rows_load(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, lds_wave, lane, rows_valid);
+    const int64_t i = min(wave_row0 + lane, N - 1); // tail lanes redo the last Gaussian and store nothing
+    const bool in_range = wave_row0 + lane < N;
 
     // outputs, defaulting to the culled values
     int o_radius = 0, o_tiles = 0;
     float o_xy[2] = {0.0f, 0.0f}, o_depth = 0.0f, o_cov[6] = {0, 0, 0, 0, 0, 0}, o_rgb[3] = {0, 0, 0};
     float o_con[4] = {0, 0, 0, 0}, o_cl[3] = {0, 0, 0};
     TileRect o_rect = {0, 0, 0, 0};
-    bool visible = false;
+    bool visible = false, need_sh = false;
 
     const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
     float p_view[4];
@@ -139,8 +147,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             const int rx1 = min(cam.grid_x, max(0, f2i((pim_x + my_radius + 16.0f - 1.0f) / 16.0f)));
             const int ry1 = min(cam.grid_y, max(0, f2i((pim_y + my_radius + 16.0f - 1.0f) / 16.0f)));
             const int tiles = (ry1 - ry0) * (rx1 - rx0);
+            need_sh = tiles != 0;
             if (tiles != 0) {
                 visible = true;
+                o_depth = p_view[2];
+                o_radius = f2i(my_radius);
+                o_xy[0] = pim_x; o_xy[1] = pim_y;
+                o_con[0] = cb2 * det_inv; o_con[1] = -cb1 * det_inv; o_con[2] = cb0 * det_inv; o_con[3] = opac[i];
+                o_tiles = tiles;
+                o_rect.x0 = (uint16_t)rx0; o_rect.y0 = (uint16_t)ry0; o_rect.x1 = (uint16_t)rx1; o_rect.y1 = (uint16_t)ry1;
+            }
+        }
+    }
+
+    __syncthreads(); // SH rows have landed in LDS
+    if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian
                 const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
                 float l2 = dx * dx;
@@ -149,15 +170,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 const float len = sqrtf(l2);
                 float x = 0.0f, y = 0.0f, z = 0.0f;
                 if (len > 0.0f) { x = dx / len; y = dy / len; z = dz / len; }
-                float sh[48];
-                const float4 *shp = reinterpret_cast<const float4 *>(shs + (size_t)i * 48);
-                const int nload = degree == 0 ? 1 : (degree == 1 ? 3 : (degree == 2 ? 7 : 12));
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < nload) v = shp[k];
-                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
-                }
+                const float *sh = reinterpret_cast<const float *>(lds_wave + lane * SH_ROW_F4);
                 const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
                 const float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
 #pragma unroll
@@ -189,15 +202,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     if (clamped) r = fmaxf(r, 0.0f);
                     o_rgb[c] = r;
                 }
-                o_depth = p_view[2];
-                o_radius = f2i(my_radius);
-                o_xy[0] = pim_x; o_xy[1] = pim_y;
-                o_con[0] = cb2 * det_inv; o_con[1] = -cb1 * det_inv; o_con[2] = cb0 * det_inv; o_con[3] = opac[i];
-                o_tiles = tiles;
-                o_rect.x0 = (uint16_t)rx0; o_rect.y0 = (uint16_t)ry0; o_rect.x1 = (uint16_t)rx1; o_rect.y1 = (uint16_t)ry1;
-            }
-        }
     }
+    if (!in_range) return;
 
     radii[i] = o_radius;
     tiles_touched[i] = o_tiles;
