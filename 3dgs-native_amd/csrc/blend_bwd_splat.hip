@@ -20,8 +20,12 @@
 // lanes write one 64-byte GradRec with float atomics (4 whole 64-B requests per wave instruction).
 //
 // Differences from the reference in float rounding only: sums over pixels/entries are re-associated
-// (quirk Q15) and 1/x uses v_rcp_f32 (1 ulp).
+// (quirk Q15), per-entry constants are factored out of the pixel sums, FMA contraction is on, and 1/x
+// uses v_rcp_f32 (1 ulp).
 #include "gsr_internal.h"
+
+// This kernel re-associates float sums anyway (quirk Q15), so fused multiply-adds are allowed here.
+#pragma clang fp contract(fast)
 
 namespace {
 
@@ -190,8 +194,13 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         head = (head + n) & (QCAP - 1);
         qn -= n;
 
-        float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
+        // Per-pixel work accumulates only the moments every gradient is linear in; the per-entry constants
+        // (conic, opacity, 0.5*W, 0.5*H) are applied once per bucket below:
+        //   h = dL/dG * G            S1 = sum h dx      S2 = sum h dy
+        //   Sxx = sum h dx^2         Sxy = sum h dx dy  Syy = sum h dy^2      Sop = sum G dL/dalpha
+        float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, S1 = 0.f, S2 = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sop = 0.f;
         bool touched = false;
+        const float na = -0.5f * a.z, nc = -0.5f * b.x, nb = -a.w;
 
         for (int q = 0; q < ((dbg & 2) ? 1 : 64); ++q) {
             const float4 pb = s_pb[q];
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const float4 pa = s_pa[q];
             const float2 carry = s_carry[q];
             const float d_x = a.x - pa.x, d_y = a.y - pa.y;
-            const float power = -0.5f * (a.z * d_x * d_x + b.x * d_y * d_y) - a.w * d_x * d_y;
+            // power = -0.5 (a dx^2 + c dy^2) - b dx dy, contracted (this file allows FMA)
+            const float power = d_x * (na * d_x + nb * d_y) + nc * d_y * d_y;
             const float G = fast_exp(power);
             const float alpha = fminf(0.99f, b.y * G);
             const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
@@ -209,31 +219,28 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const float Pi = wave_scan_mul(m);
             const float denom = carry.x * Pi;           // product of (1-alpha) over this entry and everything deeper
             const float T = pa.z * fast_rcp(denom);     // transmittance in front of this entry
-            float cd = b.z * pb.x;
-            cd += b.w * pb.y;
-            cd += colb * pb.z;
+            const float cd = b.z * pb.x + b.w * pb.y + colb * pb.z;
             const float w = alpha * T;
             const float qv = live ? w * cd : 0.0f;
             const float Qi = wave_scan_add(qv);
-            const float Qe = carry.y + (Qi - qv);       // deeper entries only
             if (lane == 63) s_carry[q] = make_float2(denom, carry.y + Qi);
             if (live) {
                 touched = true;
-                const float inv = fast_rcp(one_m);
-                const float dL_dalpha = T * cd - (Qe + pa.w) * inv;
+                const float Qe = carry.y + (Qi - qv);   // deeper entries only
+                const float dL_dalpha = T * cd - (Qe + pa.w) * fast_rcp(one_m);
                 g_c0 += w * pb.x; g_c1 += w * pb.y; g_c2 += w * pb.z;
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * d_x, gdy = G * d_y;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                g_mx += dL_dG * dG_ddelx * ddelx_dx;
-                g_my += dL_dG * dG_ddely * ddely_dy;
-                g_ca += -0.5f * gdx * d_x * dL_dG;
-                g_cb += -0.5f * gdx * d_y * dL_dG;
-                g_cc += -0.5f * gdy * d_y * dL_dG;
-                g_op += G * dL_dalpha;
+                const float gd = G * dL_dalpha;
+                Sop += gd;
+                const float h = b.y * gd;                // dL/dG * G = o * dL/dalpha * G
+                const float hx = h * d_x, hy = h * d_y;
+                S1 += hx; S2 += hy;
+                Sxx += hx * d_x; Sxy += hx * d_y; Syy += hy * d_y;
             }
         }
+        // dL/dmean2D = dL/dG * dG/ddel * 0.5*(W,H), dG/ddelx = -G (a dx + b dy); dL/dconic = -0.5 h (dx^2, dx dy, dy^2)
+        const float g_mx = -(a.z * S1 + a.w * S2) * ddelx_dx;
+        const float g_my = -(b.x * S2 + a.w * S1) * ddely_dy;
+        const float g_ca = -0.5f * Sxx, g_cb = -0.5f * Sxy, g_cc = -0.5f * Syy, g_op = Sop;
 
         // transpose through LDS: 16 lanes per entry -> one 64-byte accumulator record each
         s_id[lane] = touched ? id : -1;
