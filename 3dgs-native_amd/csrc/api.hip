@@ -37,9 +37,6 @@ int tile_bits(int tiles)
 }
 
 struct BinWs {
-    uint64_t *sort_tmp;  // [N]  ping-pong partner of GeomWs::depth_item
-    int32_t *doff;       // [N]  exclusive offsets in depth order
-    int32_t *scan_tmp;   // block sums
     int32_t *hist;       // [256 * nb]
     int32_t *totals;     // [256]
     uint64_t *tile_a;    // [D]
@@ -50,11 +47,8 @@ BinWs carve_bin(void *base, int64_t N, int64_t D)
 {
     Carver c(base);
     BinWs w;
-    const int64_t m = N > D ? N : D;
-    w.sort_tmp = c.take<uint64_t>((size_t)N);
-    w.doff = c.take<int32_t>((size_t)N);
-    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_CHUNK) + 1);
-    w.hist = c.take<int32_t>(256 * ((size_t)gsr_div_up(m, GSR_RADIX_CHUNK) + 1));
+    (void)N;
+    w.hist = c.take<int32_t>(256 * ((size_t)gsr_div_up(D, GSR_RADIX_CHUNK) + 1));
     w.totals = c.take<int32_t>(256);
     w.tile_a = c.take<uint64_t>((size_t)D);
     w.tile_b = c.take<uint64_t>((size_t)D);
@@ -125,6 +119,26 @@ inline void mark(int step, int slot, hipStream_t s)
     if (g_timer.on && step < g_timer.max_steps) (void)hipEventRecord(g_timer.at(step, slot), s);
 }
 
+// Per-device readback slot for D: 4 bytes of pinned host memory + an event, created on first use and
+// kept for the life of the process.  With them the host can wait for D alone while the GPU already
+// runs the depth sort, which does not depend on D.
+struct Readback {
+    int32_t *pinned = nullptr;
+    hipEvent_t ev = nullptr;
+};
+Readback *readback_slot()
+{
+    static thread_local Readback slots[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Readback &r = slots[dev];
+    if (!r.pinned) {
+        if (hipHostMalloc((void **)&r.pinned, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &r;
+}
+
 void read_tuning()
 {
     static bool done = false;
@@ -145,7 +159,11 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.rec = c.take<BlendRec>((size_t)N);
     w.rect = c.take<TileRect>((size_t)N);
     w.depth_item = c.take<uint64_t>((size_t)N);
+    w.sort_tmp = c.take<uint64_t>((size_t)N);
+    w.doff = c.take<int32_t>((size_t)N);
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_CHUNK) + 1);
+    w.hist = c.take<int32_t>(256 * ((size_t)gsr_div_up(N, GSR_RADIX_CHUNK) + 1));
+    w.totals = c.take<int32_t>(256);
     w.bytes = c.off + 256;
     return w;
 }
@@ -192,9 +210,24 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     mark(st, 1, s);
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, s));
     mark(st, 2, s);
-    int32_t last = 0;
-    HIP_TRY(hipMemcpyAsync(&last, geom->point_offsets + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    Readback *rb = readback_slot();
+    if (!rb) return GSR_E_HIP;
+    HIP_TRY(hipMemcpyAsync(rb->pinned, geom->point_offsets + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(rb->ev, s));
+    // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id
+    // order, four 8-bit passes over the high word; ends back in depth_item) and the depth-order offsets.
+    {
+        uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
+        for (int pass = 0; pass < 4; ++pass) {
+            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, s));
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        mark(st, 3, s);
+        HIP_TRY(gsr_launch_scan(geom->tiles_touched, ws.depth_item, ws.doff, ws.scan_tmp, N, 1, s));
+        mark(st, 4, s);
+    }
+    HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting
+    const int32_t last = *rb->pinned;
     *num_rendered = (int64_t)last;
     if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
     return GSR_OK;
@@ -228,18 +261,9 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const BinWs bw = carve_bin(bin_ws, N, D);
 
     const int st = g_timer.fwd_step;
-    mark(st, 3, s);
-    // 1. Gaussians by depth bits (stable from id order): four 8-bit passes over the high word
-    uint64_t *src = gw.depth_item, *dst = bw.sort_tmp;
-    for (int pass = 0; pass < 4; ++pass) {
-        HIP_TRY(gsr_launch_radix_pass(src, dst, bw.hist, bw.totals, N, 32 + 8 * pass, s));
-        uint64_t *t = src; src = dst; dst = t;
-    }
-    mark(st, 4, s);
-    // 2. offsets in depth order, 3. expansion to (tile, id) items
-    HIP_TRY(gsr_launch_scan(geom->tiles_touched, src, bw.doff, bw.scan_tmp, N, 1, s));
     mark(st, 5, s);
-    HIP_TRY(gsr_launch_expand(src, bw.doff, gw.rect, bw.tile_a, N, cam.grid_x, s));
+    // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile, id) items
+    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, s));
     mark(st, 6, s);
     // 4. stable partition by tile id
     uint64_t *tsrc = bw.tile_a, *tdst = bw.tile_b;

@@ -36,8 +36,12 @@ static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 struct GeomWs {
     BlendRec *rec;        // [N]
     TileRect *rect;       // [N]
-    uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled
-    int32_t *scan_tmp;    // block sums for the id-order scan
+    uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled; sorted by depth after gsr_forward_count
+    uint64_t *sort_tmp;   // [N] ping-pong partner of depth_item
+    int32_t *doff;        // [N] exclusive tile-pair offsets in depth order
+    int32_t *scan_tmp;    // block sums for the scans
+    int32_t *hist;        // [256 * nb(N)] radix block histograms
+    int32_t *totals;      // [256]
     size_t bytes;
 };
 GeomWs gsr_carve_geom(void *base, int64_t N);

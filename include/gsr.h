@@ -12,11 +12,13 @@
  * Conventions
  *   - Every pointer is a DEVICE pointer unless marked host.  The caller owns all memory, including
  *     scratch (one byte buffer per call, sized by the *_workspace_bytes functions).  The library
- *     never allocates or frees device memory and keeps no global state, so it is re-entrant for
- *     distinct buffers.  One process per GPU for multi-GPU use.
- *   - All work is enqueued on `stream` (a hipStream_t).  Only gsr_forward_count synchronises (it
- *     returns the number of (tile, Gaussian) pairs D, which sizes GsrBinning -- the reference's one
- *     unavoidable readback, forward.py:764).
+ *     never allocates or frees device memory, so it is re-entrant for distinct buffers.  One process
+ *     per GPU for multi-GPU use.
+ *   - All work is enqueued on `stream` (a hipStream_t).  Only gsr_forward_count waits on the device: for
+ *     the number of (tile, Gaussian) pairs D, which sizes GsrBinning -- the reference's one unavoidable
+ *     readback, forward.py:764.  It waits on an event behind the 4-byte copy only, so the depth sort it
+ *     has already enqueued keeps running; the one piece of state the library keeps is that per-device
+ *     pinned 4-byte slot and event (plus the optional profiling aid at the end of this header).
  *   - Layouts are the reference's packed AoS: vec3 = 3 floats, vec4 = 4 floats, VEC6 = 6 floats
  *     (xx,xy,xz,yy,yz,zz; reference forward.py:186), images row-major [y][x].  Quaternions are
  *     (x,y,z,w) (forward.py:177).  Matrices are 16 floats row-major AS STORED by the reference's
@@ -128,9 +130,10 @@ size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
 size_t gsr_backward_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
 
 /* Stage 1 of render_gaussians: wp_preprocess + wp_prefix_sum + the D readback
- * (reference forward.py:719-767).  Fills *geom, leaves per-Gaussian blend records and depth keys in
- * geom_ws (which must be passed unchanged to gsr_forward_render), and returns D in *num_rendered
- * (host pointer).  Synchronises `stream`.  GSR_E_OVERFLOW if D > GSR_MAX_RENDERED. */
+ * (reference forward.py:719-767), plus the part of the sort that does not depend on D (Gaussians by
+ * depth).  Fills *geom, leaves per-Gaussian blend records, depth-sorted ids and offsets in geom_ws
+ * (which must be passed unchanged to gsr_forward_render), and returns D in *num_rendered (host
+ * pointer).  GSR_E_OVERFLOW if D > GSR_MAX_RENDERED. */
 int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom,
                       void *geom_ws, size_t geom_ws_bytes, int64_t *num_rendered, void *stream);
 
@@ -156,10 +159,10 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
  * stage over the steps recorded since enabling, and clears the record. */
 enum {
     GSR_ST_PREPROCESS = 0, /* preprocess_kernel */
-    GSR_ST_SCAN,           /* id-order scan of tiles_touched (3 kernels) */
-    GSR_ST_COUNT_SYNC,     /* D readback */
-    GSR_ST_DEPTH_SORT,     /* 4 radix passes over N items */
+    GSR_ST_SCAN,           /* id-order scan of tiles_touched (3 kernels) + async D readback */
+    GSR_ST_DEPTH_SORT,     /* 4 radix passes over N items (overlaps the host's wait for D) */
     GSR_ST_DEPTH_SCAN,     /* depth-order offsets */
+    GSR_ST_HOST_GAP,       /* stream idle between gsr_forward_count and gsr_forward_render (host round trip) */
     GSR_ST_EXPAND,         /* (tile,id) item expansion */
     GSR_ST_TILE_SORT,      /* radix passes over D items */
     GSR_ST_RANGES,         /* point_list + ranges */
