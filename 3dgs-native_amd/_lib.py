@@ -26,7 +26,7 @@ class GsrCamera(C.Structure):
 
 class GsrGeom(C.Structure):
     _fields_ = [("radii", vp), ("tiles_touched", vp), ("point_offsets", vp), ("xy", vp), ("depths", vp), ("cov3D", vp),
-                ("rgb", vp), ("conic_opacity", vp), ("clamped_state", vp)]
+                ("rgb", vp), ("conic_opacity", vp), ("clamped_state", vp), ("blend_records", vp)]
 
 
 class GsrBinning(C.Structure):

@@ -263,7 +263,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const int st = g_timer.fwd_step;
     mark(st, 5, s);
     // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile, id) items
-    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, s));
+    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, D, s));
     mark(st, 6, s);
     // 4. stable partition by tile id
     uint64_t *tsrc = bw.tile_a, *tdst = bw.tile_b;
@@ -304,11 +304,15 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     const int st = g_timer.bwd_step;
     mark(st, 10, s);
     HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
-    if (D > 0) HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));
+    const BlendRec *records = (const BlendRec *)geom->blend_records;
+    if (D > 0 && !records) {
+        HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));
+        records = bw.rec;
+    }
     mark(st, 11, s);
     if (D > 0) {
-        if (gsr_bwd_mode == 1) HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
-        else HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, bw.rec, *image, dL_dpixels, bw.acc, s));
+        if (gsr_bwd_mode == 1) HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
+        else HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
     }
     mark(st, 12, s);
     HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));

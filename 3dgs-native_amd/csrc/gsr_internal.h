@@ -61,7 +61,7 @@ hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *his
                                  int64_t n, int shift, hipStream_t s);
 
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect,
-                             uint64_t *tile_items, int64_t n, int grid_x, hipStream_t s);
+                             uint64_t *tile_items, int64_t n, int grid_x, int64_t D, hipStream_t s);
 hipError_t gsr_launch_ranges(const uint64_t *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D,
                              hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,

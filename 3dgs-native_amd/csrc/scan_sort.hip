@@ -247,19 +247,47 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
 // expansion: depth-ordered Gaussians -> (tile << 32 | id) items, row-major tile walk
 // (same walk as reference forward.py:546-548: y outer, x inner)
 // ---------------------------------------------------------------------------------------------
+// Load-balanced: a wave owns 64 consecutive depth-sorted Gaussians, whose output range
+// [doff[k0], doff[k0+64]) is contiguous.  Lanes walk that range 64 items at a time (fully coalesced
+// 8-byte stores) and find each item's owner by a 6-step binary search over the wave's 64 offsets in
+// LDS, so a Gaussian covering thousands of tiles costs no more per item than one covering four.
 __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ doff,
                                                      const TileRect *__restrict__ rect, uint64_t *__restrict__ tile_items, int64_t n,
-                                                     int grid_x)
+                                                     int grid_x, int64_t D)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint64_t it = sorted[k];
-    if ((uint32_t)(it >> 32) == 0xFFFFFFFFu) return; // culled (sorted to the end)
-    const uint32_t id = (uint32_t)it;
-    const TileRect rc = rect[id];
-    int64_t o = doff[k];
-    for (int y = rc.y0; y < rc.y1; ++y)
-        for (int x = rc.x0; x < rc.x1; ++x) tile_items[o++] = ((uint64_t)(uint32_t)(y * grid_x + x) << 32) | id;
+    __shared__ int s_off[4][64];
+    __shared__ TileRect s_rect[4][64];
+    __shared__ uint32_t s_gid[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t k0 = (int64_t)blockIdx.x * 256 + w * 64;
+    const int64_t k = k0 + lane;
+    int off = (int)D;
+    TileRect rc = {0, 0, 0, 0};
+    uint32_t id = 0;
+    if (k < n) {
+        const uint64_t it = sorted[k];
+        id = (uint32_t)it;
+        off = doff[k];
+        if ((uint32_t)(it >> 32) != 0xFFFFFFFFu) rc = rect[id]; // culled Gaussians (sorted last) own no items
+    }
+    s_off[w][lane] = off;
+    s_rect[w][lane] = rc;
+    s_gid[w][lane] = id;
+    __syncthreads();
+    if (k0 >= n) return;
+    const int begin = s_off[w][0];
+    const int end = (k0 + 64 < n) ? doff[k0 + 64] : (int)D;
+    for (int j = begin + lane; j < end; j += 64) {
+        int lo = 0; // last k with off[k] <= j (zero-count Gaussians share their successor's offset)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (s_off[w][lo + step] <= j) lo += step;
+        const TileRect r = s_rect[w][lo];
+        const int t = j - s_off[w][lo];
+        const int wd = (int)r.x1 - (int)r.x0;
+        const int y = t / wd, x = t - y * wd; // row-major walk: y outer, x inner (reference forward.py:546-548)
+        tile_items[j] = ((uint64_t)(uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x) << 32) | s_gid[w][lo];
+    }
 }
 
 // sorted tile items -> point_list + tile ranges (reference forward.py:561-586); ranges pre-zeroed
@@ -313,11 +341,11 @@ hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *his
 }
 
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, uint64_t *tile_items,
-                             int64_t n, int grid_x, hipStream_t s)
+                             int64_t n, int grid_x, int64_t D, hipStream_t s)
 {
-    if (n <= 0) return hipSuccess;
+    if (n <= 0 || D <= 0) return hipSuccess;
     hipLaunchKernelGGL(expand_kernel, dim3((unsigned)gsr_div_up(n, 256)), dim3(256), 0, s, sorted_depth_items, doff, rect, tile_items,
-                       n, grid_x);
+                       n, grid_x, D);
     return hipGetLastError();
 }
 

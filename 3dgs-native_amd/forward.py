@@ -40,7 +40,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     xy, depths, cov3Ds, rgb = e((N, 2), f32), e((N,), f32), e((N, 6), f32), e((N, 3), f32)
     conic_opacity, clamped_state = e((N, 4), f32), e((N, 3), f32)
     geom = _lib.GsrGeom(_host.ptr(radii), _host.ptr(tiles_touched), _host.ptr(point_offsets), _host.ptr(xy), _host.ptr(depths),
-                        _host.ptr(cov3Ds), _host.ptr(rgb), _host.ptr(conic_opacity), _host.ptr(clamped_state))
+                        _host.ptr(cov3Ds), _host.ptr(rgb), _host.ptr(conic_opacity), _host.ptr(clamped_state), None)
     image, depth_image = e((H, W, 3), f32), e((H, W), f32)
     final_Ts, n_contrib = e((H, W), f32), e((H, W), i32)
     img = _lib.GsrImage(_host.ptr(image), _host.ptr(depth_image), _host.ptr(final_Ts), _host.ptr(n_contrib))
@@ -49,6 +49,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
 
     with torch.cuda.device(dev):
         gws = _host.workspace("geom", L.gsr_geom_workspace_bytes(N), dev)
+        _host.workspace_written(gws)
         D = C.c_int64(0)
         _lib.check(L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), _host.ptr(gws), gws.numel(),
                                        C.byref(D), stream))
@@ -60,6 +61,11 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
         _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
                                         _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
+    # Let a following backward() reuse the packed blend records this call left in the geom workspace:
+    # the tag rides on the means2D tensor (the reference's callers re-pack the dicts by hand, train.py:986-1000)
+    # and is honoured only while no later forward has overwritten that workspace.
+    if N > 0:
+        xy._gsr_records = _host.tag_records(gws, N)
     return image, depth_image, {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
         "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,

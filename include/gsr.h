@@ -90,6 +90,9 @@ typedef struct GsrGeom {
     float *rgb;             /* [N*3] */
     float *conic_opacity;   /* [N*4] */
     float *clamped_state;   /* [N*3] */
+    const void *blend_records; /* optional, gsr_backward only: the N 64-byte blend records gsr_forward_count
+                                  left at the START of geom_ws, if the caller still holds that buffer
+                                  unmodified; NULL -> rebuilt from xy / conic_opacity / rgb (same values) */
 } GsrGeom;
 
 /* Sorted (tile, depth) list: dict entries point_list / ranges. */

@@ -50,7 +50,7 @@ def test_struct_layouts_match_header():
     _lib = sub("_lib")
     assert C.sizeof(_lib.GsrCamera) == (16 + 16 + 3 + 3 + 2 + 2) * 4 + 2 * 4
     assert C.sizeof(_lib.GsrScene) == 8 + 5 * 8 + 3 * 4 + 4   # trailing pad to 8
-    assert C.sizeof(_lib.GsrGeom) == 9 * 8 and C.sizeof(_lib.GsrGrads) == 8 * 8
+    assert C.sizeof(_lib.GsrGeom) == 10 * 8 and C.sizeof(_lib.GsrGrads) == 8 * 8
     assert C.sizeof(_lib.GsrBinning) == 24 and C.sizeof(_lib.GsrImage) == 32
     assert _lib.GsrCamera.focal_x.offset == (16 + 16 + 3 + 3 + 2) * 4
 
