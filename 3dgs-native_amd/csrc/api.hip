@@ -48,7 +48,7 @@ BinWs carve_bin(void *base, int64_t N, int64_t D)
     Carver c(base);
     BinWs w;
     (void)N;
-    w.hist = c.take<int32_t>(256 * ((size_t)gsr_div_up(D, GSR_RADIX_CHUNK) + 1));
+    w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(D) + 1));
     w.totals = c.take<int32_t>(256);
     w.tile_a = c.take<uint64_t>((size_t)D);
     w.tile_b = c.take<uint64_t>((size_t)D);
@@ -162,7 +162,7 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.sort_tmp = c.take<uint64_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_CHUNK) + 1);
-    w.hist = c.take<int32_t>(256 * ((size_t)gsr_div_up(N, GSR_RADIX_CHUNK) + 1));
+    w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
     w.totals = c.take<int32_t>(256);
     w.bytes = c.off + 256;
     return w;

@@ -116,16 +116,19 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 // ---------------------------------------------------------------------------------------------
 // stable radix pass (8-bit digit) on 64-bit items
 // ---------------------------------------------------------------------------------------------
-constexpr int RADIX_ITEMS = GSR_RADIX_CHUNK / 256; // rounds per wave (each wave owns 64*RADIX_ITEMS consecutive items)
+// Chunk = 256 * ITEMS items per block (each wave owns 64*ITEMS consecutive items).  ITEMS = 16 for the big
+// D-item passes (fewer, fatter blocks); ITEMS = 4 when n is small, so the launch still fills the chip.
 
 // block histogram of the digit; hist is digit-major [256][nb]
+template <int RADIX_ITEMS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restrict__ in, int32_t *__restrict__ hist, int64_t n,
                                                          int shift, int nb)
 {
+    constexpr int CHUNK = 256 * RADIX_ITEMS;
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * GSR_RADIX_CHUNK;
+    const int64_t base = (int64_t)blockIdx.x * CHUNK;
 #pragma unroll 4
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = base + r * 256 + threadIdx.x;
@@ -152,18 +155,20 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict_
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <int RADIX_ITEMS>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
                                                             int64_t n, int shift, int nb)
 {
-    __shared__ uint64_t s_items[GSR_RADIX_CHUNK]; // 32 KiB: items reordered by digit
+    constexpr int CHUNK = 256 * RADIX_ITEMS;
+    __shared__ uint64_t s_items[CHUNK]; // 32 KiB: items reordered by digit
     __shared__ int s_wcnt[4][256];                 // per-wave digit counts -> per-wave start offsets
     __shared__ int s_dstart[256];                  // first LDS slot of each digit
     __shared__ int s_gbase[256];                   // global position of the block's first item of each digit
     __shared__ int s_tmp[4];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t block_base = (int64_t)blockIdx.x * GSR_RADIX_CHUNK;
+    const int64_t block_base = (int64_t)blockIdx.x * CHUNK;
     const int64_t wave_base = block_base + (int64_t)w * 64 * RADIX_ITEMS;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     __syncthreads();
 
     // pass 3: contiguous runs out to global memory
-    const int valid_n = (int)((n - block_base) < GSR_RADIX_CHUNK ? (n - block_base) : GSR_RADIX_CHUNK);
+    const int valid_n = (int)((n - block_base) < CHUNK ? (n - block_base) : CHUNK);
 #pragma unroll 4
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int slot = r * 256 + tid;
@@ -333,10 +338,17 @@ hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *his
                                  hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, totals, nb);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    if (n <= GSR_RADIX_SMALL_N) {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
+        hipLaunchKernelGGL(radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, totals, nb);
+        hipLaunchKernelGGL(radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    } else {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
+        hipLaunchKernelGGL(radix_hist_kernel<GSR_RADIX_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, totals, nb);
+        hipLaunchKernelGGL(radix_scatter_kernel<GSR_RADIX_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    }
     return hipGetLastError();
 }
 
