@@ -73,14 +73,19 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     int last = 0;
     bool done = !(pix_x < W && pix_y < H);
 
+    // software pipeline: the gather of batch k+1 (id, then its 64-byte record) is in flight while batch k is blended
+    int nid = (start + tid < end) ? point_list[start + tid] : -1;
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, ncd = na;
+    if (nid >= 0) {
+        const float4 *rp = reinterpret_cast<const float4 *>(rec + nid);
+        na = rp[0]; nb = rp[1]; ncd = rp[2];
+    }
     for (int base = start; base < end; base += BATCH) {
         if (__syncthreads_and(done)) break; // whole tile saturated (also fences LDS reuse)
 
         const int cnt = min(BATCH, end - base);
         if (tid < cnt) {
-            const int id = point_list[base + tid];
-            const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
-            const float4 a = rp[0], b = rp[1], c = rp[2];
+            const float4 a = na, b = nb, c = ncd;
             s_a[tid] = a;
             s_b[tid] = b;
             s_c[tid] = make_float2(c.x, c.y);
@@ -93,6 +98,15 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             }
             s_mask[tid] = m;
         }
+        // issue the next batch's gather now; it completes under the blend loop below
+        {
+            const int nidx = base + BATCH + tid;
+            nid = (nidx < end) ? point_list[nidx] : -1;
+            if (nid >= 0) {
+                const float4 *rp = reinterpret_cast<const float4 *>(rec + nid);
+                na = rp[0]; nb = rp[1]; ncd = rp[2];
+            }
+        }
         __syncthreads();
 
         if (__all(done)) continue; // this wave has nothing left; keep serving the barriers
@@ -102,12 +116,16 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         for (int g = 0; g < cnt && !stop; g += 64) {
             const int mv = (g + lane < cnt) ? s_mask[g + lane] : 0;
             unsigned long long bits = __ballot((mv & mybit) != 0);
-            while (bits) {
-                const int j = g + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float2 c = s_c[j];
+            if (!bits) continue;
+            int j = g + __builtin_ctzll(bits);
+            bits &= bits - 1;
+            float4 a = s_a[j], b = s_b[j];
+            float2 c = s_c[j];
+            for (;;) {
+                // LDS reads of the next live entry are issued before this one is blended
+                const int jn = bits ? g + __builtin_ctzll(bits) : j;
+                const float4 a2 = s_a[jn], b2 = s_b[jn];
+                const float2 c2 = s_c[jn];
                 const float dx = a.x - pixf_x, dy = a.y - pixf_y;
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 const float alpha = fminf(0.99f, b.y * fast_exp(power));
@@ -126,6 +144,9 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
                 if (__any(sat)) { // wave-uniform: only re-check saturation when some lane just saturated
                     if (__all(done)) { stop = true; break; }
                 }
+                if (!bits) break;
+                bits &= bits - 1;
+                j = jn; a = a2; b = b2; c = c2;
             }
         }
     }
