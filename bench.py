@@ -35,19 +35,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 
 
 def stage_bytes(N, Nv, D, P, Tn):
-    """Algorithmic HBM bytes per launch of each timed stage (DESIGN.md 'Kernels and rooflines')."""
+    """Algorithmic HBM bytes per launch of each timed stage.  The per-unit figures are SURVEY.md section 8(d)'s
+    (compulsory traffic: every input read once, every output written once, every list entry read once per
+    tile) for the stages the reference has, and the same counting rule for the stages of our own binning
+    design."""
     return {
-        "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv + 80 * N,   # + 64 B record, 8 B rect, 8 B depth item
+        "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv,
         "scan": 8 * N,
-        "depth_sort": 4 * 24 * N,
+        "depth_sort": 4 * 24 * N,             # 4 passes x (8 B histogram read + 8 B read + 8 B write) per item
         "depth_scan": 16 * N,
         "expand": 20 * Nv + 8 * D,
         "tile_sort": 2 * 24 * D,
         "ranges": 12 * D + 8 * Tn,
-        "blend_fwd": 68 * D + 8 * Tn + 24 * P,
-        "bwd_prep": 64 * N + 40 * N + 64 * N,
-        "blend_bwd": 68 * D + 8 * Tn + 20 * P + 36 * Nv,
-        "geom_bwd": 64 * N + 4 * N + 300 * Nv + 276 * N,
+        "blend_fwd": 44 * D + 8 * Tn + 24 * P,
+        "bwd_prep": 64 * N,
+        "blend_bwd": 40 * D + 20 * P + 44 * N,
+        "geom_bwd": 4 * N + 308 * Nv + 232 * N,
     }
 
 
