@@ -148,6 +148,7 @@ void read_tuning()
     if (const char *e = getenv("GSR_BWD_P")) gsr_bwd_p_override = atoi(e);
     if (const char *e = getenv("GSR_BWD_MODE")) gsr_bwd_mode = atoi(e);
     if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e);
+    if (const char *e = getenv("GSR_BWD_BLOCK")) gsr_bwd_block = atoi(e);
 }
 
 } // namespace

@@ -9,8 +9,8 @@
 //     P_k = prod_{deeper j <= k} (1 - alpha_j)        ->  T_k = T_final / P_k          (backward.py:658)
 //     Q_k = sum_{deeper j <  k} alpha_j T_j (c_j . dL_dpixel)  ( = T_k (1-alpha_k) accum_rec . dL_dpixel, :667-671)
 // so that dL_dalpha_k = T_k (c_k . dL_dpixel) - (Q_k + T_final bg . dL_dpixel) / (1 - alpha_k)   (:671-680).
-// One single-wave workgroup per 8x8 pixel block (4 per tile, 10 000 at 800x800) replays its tile's
-// list back to front.  Most entries of a tile's list cannot touch a given 8x8 block, so the wave first
+// One single-wave workgroup per 8x4 pixel block (8 per tile, 20 000 at 800x800; 8x8 and 4x4 are also
+// instantiated) replays its tile's list back to front.  Most entries of a tile's list cannot touch a given block, so the wave first
 // COMPACTS the stream: 64 candidates at a time are tested against the block rectangle (exact convex
 // minimum of the conic over the rectangle vs ln(255 o), conservative) and survivors are queued in an
 // LDS ring in order; each full bucket of 64 survivors (lane 0 = deepest) then runs the pixel loop, so

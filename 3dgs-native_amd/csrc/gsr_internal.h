@@ -89,3 +89,4 @@ extern int gsr_blend_p_override;   // GSR_BLEND_P  : pixels per lane in blend_fo
 extern int gsr_bwd_p_override;     // GSR_BWD_P    : pixels per lane in the pixel-parallel backward
 extern int gsr_bwd_mode;           // GSR_BWD_MODE : 0 = Gaussian-parallel backward (default), 1 = pixel-parallel
 extern int gsr_debug_flags;        // GSR_DEBUG    : timing ablations (wrong results), never set in production
+extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)
