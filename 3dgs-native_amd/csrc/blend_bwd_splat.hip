@@ -85,12 +85,12 @@ __device__ __forceinline__ float edge_min_q(float qa, float qb, float qc, float 
     v = fminf(vhi, fmaxf(vlo, v));
     return 0.5f * (qa * u * u + qc * v * v) + qb * u * v;
 }
-__device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float opacity, float x0, float y0)
+__device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float opacity, float x0, float y0, float ex, float ey)
 {
     if (!(opacity * 255.0f >= 1.0f)) return false;
     const float tau = __logf(opacity * 255.0f); // >= 0
-    // d = g - pixel, pixel in [x0, x0+7] -> d in [gx-x0-7, gx-x0]
-    const float dxl = gx - (x0 + 7.0f), dxh = gx - x0, dyl = gy - (y0 + 7.0f), dyh = gy - y0;
+    // d = g - pixel, pixel in [x0, x0+ex] -> d in [gx-x0-ex, gx-x0]
+    const float dxl = gx - (x0 + ex), dxh = gx - x0, dyl = gy - (y0 + ey), dyh = gy - y0;
     float qmin;
     if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) qmin = 0.0f;
     else {
@@ -104,6 +104,7 @@ __device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, floa
 
 constexpr int QCAP = 128; // ring of compacted entries (power of two, >= 2*64 - 1)
 
+template <int BW, int BH>
 __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
                                                                   const int32_t *__restrict__ ranges,
                                                                   const int32_t *__restrict__ point_list,
@@ -112,25 +113,28 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                                                                   const int32_t *__restrict__ n_contrib,
                                                                   const float *__restrict__ dL_dpixels, GradRec *__restrict__ acc, int dbg)
 {
-    __shared__ float4 s_pa[64];     // px, py, Tfin, bgdot*Tfin
-    __shared__ float4 s_pb[64];     // dpix r,g,b, kept (as int bits)
-    __shared__ float2 s_carry[64];  // P (product of deeper (1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
+    constexpr int NPIX = BW * BH;            // pixels of the block this wave owns
+    constexpr int PER_TILE = 256 / NPIX;     // blocks per 16x16 tile
+    constexpr int NBX = 16 / BW;
+    __shared__ float4 s_pa[NPIX];   // px, py, Tfin, bgdot*Tfin
+    __shared__ float4 s_pb[NPIX];   // dpix r,g,b, kept (as int bits)
+    __shared__ float2 s_carry[NPIX]; // P (product of deeper (1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
     __shared__ int2 s_ring[QCAP];   // compacted survivors: (Gaussian id, list index); records are re-gathered (L2 hits)
     __shared__ float s_g[64][9];    // per-entry gradients for the transposed flush (odd stride: no bank conflicts)
     __shared__ int s_id[64];
 
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    const int tile = blockIdx.x / PER_TILE, sub = blockIdx.x % PER_TILE;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
     const int start = range.x, end = range.y;
     if (end <= start) return;
 
     // lane q prepares the constants of pixel q of the block
-    const int bx0 = tile_x * 16 + (sub & 1) * 8, by0 = tile_y * 16 + (sub >> 1) * 8;
-    const int my_x = bx0 + (lane & 7), my_y = by0 + (lane >> 3);
+    const int bx0 = tile_x * 16 + (sub % NBX) * BW, by0 = tile_y * 16 + (sub / NBX) * BH;
+    const int my_x = bx0 + (lane % BW), my_y = by0 + (lane / BW);
     int kept = start;
-    {
+    if (lane < NPIX) {
         float Tfin = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
         if (my_x < W && my_y < H) {
             const size_t px = (size_t)my_y * W + my_x;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                 id = point_list[idx];
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
                 const float4 a = rp[0], b = rp[1];
-                hit = block_may_hit(a.x, a.y, a.z, a.w, b.x, b.y, fx0, fy0);
+                hit = block_may_hit(a.x, a.y, a.z, a.w, b.x, b.y, fx0, fy0, (float)(BW - 1), (float)(BH - 1));
             }
             const unsigned long long m = __ballot(hit);
             if (hit) s_ring[(head + qn + __popcll(m & lt_mask)) & (QCAP - 1)] = make_int2(id, idx);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         bool touched = false;
         const float na = -0.5f * a.z, nc = -0.5f * b.x, nb = -a.w;
 
-        for (int q = 0; q < ((dbg & 2) ? 1 : 64); ++q) {
+        for (int q = 0; q < ((dbg & 2) ? 1 : NPIX); ++q) {
             const float4 pb = s_pb[q];
             const int pkept = __float_as_int(pb.w);
             if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
 
 } // namespace
 
+int gsr_bwd_block = 32;
 int gsr_debug_flags = 0; // GSR_DEBUG: bit0 = skip atomics, bit1 = one pixel per bucket (timing ablations only)
 
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
@@ -267,7 +272,15 @@ hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *range
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(blend_backward_splat_kernel, dim3(tiles * 4), dim3(64), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1],
-                       cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels, acc, gsr_debug_flags);
+#define LAUNCH(BW, BH)                                                                                                        \
+    hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH>), dim3(tiles * (256 / ((BW) * (BH)))), dim3(64), 0, s, cam.W, cam.H,  \
+                       cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib,      \
+                       dL_dpixels, acc, gsr_debug_flags)
+    switch (gsr_bwd_block) { // pixels per wave: GSR_BWD_BLOCK = 32 (8x4, default: measured best at C3), 64 (8x8), 16 (4x4)
+    case 16: LAUNCH(4, 4); break;
+    case 64: LAUNCH(8, 8); break;
+    default: LAUNCH(8, 4); break;
+    }
+#undef LAUNCH
     return hipGetLastError();
 }

@@ -10,7 +10,10 @@
 // All sorting is one kernel family: a stable LSD radix pass over 64-bit items on an 8-bit digit.
 // Wave64 ballots give each item its rank among equal digits (no per-item atomics), an LDS reorder
 // makes the scatter write contiguous runs.  No inter-workgroup spin-waits anywhere: every dependency
-// is a kernel boundary.
+// is a kernel boundary.  (A single-kernel-per-pass variant with ticketed chunks and decoupled look-back
+// over 8-byte sc1 status words was built and measured in round 1: bit-identical output but 1.4-2.1x
+// SLOWER on MI355X -- depth sort 0.196 vs 0.093 ms, tile sort 0.187 vs 0.131 ms at C3 -- because every
+// look-back hop is a ~1-3 us memory-side round trip and all chunks run in lockstep; see DESIGN.md.)
 #include "gsr_internal.h"
 
 namespace {
