@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend; nccl is RCCL (default). gloo + "
+                    "--single-device rehearse the N>1 path on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -74,11 +77,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    torch.cuda.set_device(local_rank if (world > 1 and not args.single_device) else 0)
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
     gsr = importlib.import_module("3dgs-native_amd")
     cfg = gsr.scenes.CONFIGS[args.config]
