@@ -162,7 +162,7 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.depth_item = c.take<uint64_t>((size_t)N);
     w.sort_tmp = c.take<uint64_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);
-    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_CHUNK) + 1);
+    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
     w.totals = c.take<int32_t>(256);
     w.bytes = c.off + 256;

@@ -49,9 +49,9 @@ GeomWs gsr_carve_geom(void *base, int64_t N);
 // ---- launchers (host functions; each enqueues on `s` and returns hipGetLastError()) ----
 hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s);
 
-// Device-wide scan of int32 (CHUNK items per block).  mode 0: out[i] = inclusive scan of in[i].
+// Device-wide scan of int32.  mode 0: out[i] = inclusive scan of in[i].
 // mode 1: values gathered through sorted depth items: v[k] = in[low32(items[k])], out = exclusive scan.
-#define GSR_SCAN_CHUNK 4096
+#define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
                            int64_t n, int mode, hipStream_t s);
 

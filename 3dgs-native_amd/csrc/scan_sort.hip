@@ -52,33 +52,40 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *lds4 /* >= 4 ints
 }
 
 // ---------------------------------------------------------------------------------------------
-// device-wide scan: reduce -> single-block scan of block sums -> rescan with offsets
+// device-wide scan: per-wave sums -> single-block scan of the sums -> per-wave rescan with offsets.
+// The unit of work is a WAVE owning 1024 consecutive items, walked in 16 rounds of 64 so every load and
+// store is a fully coalesced 256-byte access and no block barrier is needed.  In gather mode (values
+// fetched through the depth-sorted ids, 4-byte random reads) the first kernel parks the gathered value
+// in `out`, so the random gather happens once and the second kernel streams.
 // ---------------------------------------------------------------------------------------------
-constexpr int SCAN_ITEMS = GSR_SCAN_CHUNK / 256; // items per thread (blocked arrangement)
-
-template <int MODE>
-__device__ __forceinline__ int scan_load(const int32_t *__restrict__ in, const uint64_t *__restrict__ items, int64_t k, int64_t n)
-{
-    if (k >= n) return 0;
-    if (MODE == 0) return in[k];
-    return in[(uint32_t)items[k]];
-}
+constexpr int SCAN_WAVE_ITEMS = 1024;
+constexpr int SCAN_ROUNDS = SCAN_WAVE_ITEMS / 64;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restrict__ in, const uint64_t *__restrict__ items,
-                                                          int32_t *__restrict__ block_sums, int64_t n)
+                                                          int32_t *__restrict__ out, int32_t *__restrict__ wave_sums, int64_t n)
 {
-    __shared__ int lds[4];
-    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_CHUNK;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t base = wid * SCAN_WAVE_ITEMS;
+    if (base >= n) return;
     int s = 0;
+#pragma unroll 4
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        const int64_t k = base + r * 64 + lane;
+        int v = 0;
+        if (k < n) {
+            if (MODE == 0) v = in[k];
+            else { v = in[(uint32_t)items[k]]; out[k] = v; }
+        }
+        s += v;
+    }
 #pragma unroll
-    for (int r = 0; r < SCAN_ITEMS; ++r) s += scan_load<MODE>(in, items, base + r * 256 + threadIdx.x, n);
-    int tot;
-    block_incl_scan_256(s, lds, &tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) wave_sums[wid] = s;
 }
 
-// exclusive scan of block_sums[0..nb) in place, one 256-thread block looping over 256-wide slabs
+// exclusive scan of sums[0..nb) in place, one 256-thread block looping over 256-wide slabs
 __global__ __launch_bounds__(256) void scan_mid_kernel(int32_t *__restrict__ block_sums, int nb)
 {
     __shared__ int lds[4];
@@ -94,25 +101,21 @@ __global__ __launch_bounds__(256) void scan_mid_kernel(int32_t *__restrict__ blo
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const uint64_t *__restrict__ items,
-                                                         const int32_t *__restrict__ block_sums, int32_t *__restrict__ out, int64_t n)
+__global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
+                                                         int32_t *__restrict__ out, int64_t n)
 {
-    __shared__ int lds[4];
-    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    int v[SCAN_ITEMS];
-    int s = 0;
-#pragma unroll
-    for (int r = 0; r < SCAN_ITEMS; ++r) {
-        v[r] = scan_load<MODE>(in, items, base + r, n);
-        s += v[r];
-    }
-    int tot;
-    const int inc = block_incl_scan_256(s, lds, &tot);
-    int run = block_sums[blockIdx.x] + inc - s; // exclusive prefix of this thread's first item
-#pragma unroll
-    for (int r = 0; r < SCAN_ITEMS; ++r) {
-        if (MODE == 0) { run += v[r]; if (base + r < n) out[base + r] = run; }      // inclusive
-        else { if (base + r < n) out[base + r] = run; run += v[r]; }                 // exclusive
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t base = wid * SCAN_WAVE_ITEMS;
+    if (base >= n) return;
+    int carry = wave_sums[wid];
+#pragma unroll 4
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        const int64_t k = base + r * 64 + lane;
+        const int v = (k < n) ? (MODE == 0 ? in[k] : out[k]) : 0; // gather mode: the value was parked in out by the first kernel
+        const int inc = wave_incl_scan(v);
+        if (k < n) out[k] = carry + (MODE == 0 ? inc : inc - v);  // mode 0 inclusive, mode 1 exclusive
+        carry += __shfl(inc, 63, 64);
     }
 }
 
@@ -324,15 +327,16 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
                            hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    const int nb = (int)gsr_div_up(n, GSR_SCAN_CHUNK);
+    const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
+    const int nb = (nw + 3) / 4;
     if (mode == 0) {
-        hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, n);
-        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nb);
-        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, out, n);
+        hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
+        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nw);
+        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n);
     } else {
-        hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, n);
-        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nb);
-        hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, block_tmp, out, n);
+        hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
+        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nw);
+        hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n);
     }
     return hipGetLastError();
 }
