@@ -42,6 +42,16 @@ class GsrGrads(C.Structure):
                 ("dL_dcolor", vp), ("dL_dmean2D", vp), ("dL_dconic", vp)]
 
 
+class GsrAdamGroup(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("m", vp), ("v", vp), ("lr", C.c_float)]
+
+
+class GsrAdam(C.Structure):
+    _fields_ = [("N", C.c_int64), ("pos", GsrAdamGroup), ("scale", GsrAdamGroup), ("rot", GsrAdamGroup),
+                ("opacity", GsrAdamGroup), ("sh", GsrAdamGroup), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("iteration", C.c_int32)]
+
+
 EXPORTS = {
     "gsr_abi_version": (C.c_int, []),
     "gsr_strerror": (C.c_char_p, [C.c_int]),
@@ -54,6 +64,8 @@ EXPORTS = {
                                      C.POINTER(GsrImage), vp, C.c_size_t, vp, C.c_size_t, vp]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
                                C.POINTER(GsrImage), vp, C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
+    "gsr_l1_loss_grad": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
+    "gsr_adam_update": (C.c_int, [C.POINTER(GsrAdam), vp]),
     "gsr_stage_timing": (C.c_int, [C.c_int, C.c_int]),
     "gsr_stage_times": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }

@@ -1,0 +1,171 @@
+// train_ops.hip -- the two HBM-bound steps either side of the rasterizer in a training iteration
+// (SURVEY.md section 8(f) rows f2 and f3): L1 loss + pixel gradient, and the fused Adam update.
+#include <math.h>
+
+#include "gsr_internal.h"
+
+namespace {
+
+// ---- f2: reference loss.py:12-31 (l1_loss_kernel) + :122-146 (backprop_l1_pixel_gradients) in one pass ----
+// Flat over H*W*3 floats, float4 per lane (the image is packed vec3, so any 16-byte group is valid).
+__global__ __launch_bounds__(256) void l1_loss_grad_kernel(const float *__restrict__ rendered, const float *__restrict__ target,
+                                                           float *__restrict__ pixel_grad, float *__restrict__ loss_sum, int64_t n,
+                                                           float l1_weight)
+{
+    __shared__ float s_part[4];
+    float acc = 0.0f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 r = reinterpret_cast<const float4 *>(rendered)[i];
+        const float4 t = reinterpret_cast<const float4 *>(target)[i];
+        const float d0 = r.x - t.x, d1 = r.y - t.y, d2 = r.z - t.z, d3 = r.w - t.w;
+        acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+        if (pixel_grad)
+            reinterpret_cast<float4 *>(pixel_grad)[i] = make_float4(l1_weight * (d0 < 0.0f ? -1.0f : 1.0f), l1_weight * (d1 < 0.0f ? -1.0f : 1.0f),
+                                                                    l1_weight * (d2 < 0.0f ? -1.0f : 1.0f), l1_weight * (d3 < 0.0f ? -1.0f : 1.0f));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { // tail (< 4 floats)
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float d = rendered[i] - target[i];
+        acc += fabsf(d);
+        if (pixel_grad) pixel_grad[i] = l1_weight * (d < 0.0f ? -1.0f : 1.0f);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// ---- f3: reference optimizer.py:7-139 (adam_update) ----
+struct AdamK {
+    float beta1, beta2, omb1, omb2, eps, bc1, bc2;
+};
+
+// one element of the vec3 groups (positions, scales, SH): wp_vec3_div_element adds 1e-9 to the denominator
+__device__ __forceinline__ float adam_vec3_elem(float p, float g, float &m, float &v, float lr, const AdamK &k)
+{
+    m = k.beta1 * m + k.omb1 * g;
+    v = k.beta2 * v + k.omb2 * (g * g);
+    const float mc = m / k.bc1, vc = v / k.bc2;
+    const float denom = sqrtf(vc) + k.eps;
+    return p - lr * (mc / (denom + 1e-9f));
+}
+
+// positions, scales, rotations, opacities: one thread per Gaussian
+__global__ __launch_bounds__(256) void adam_small_kernel(int64_t N, float *__restrict__ pos, const float *__restrict__ gpos, float *__restrict__ mpos,
+                                                         float *__restrict__ vpos, float lr_pos, float *__restrict__ scl,
+                                                         const float *__restrict__ gscl, float *__restrict__ mscl, float *__restrict__ vscl,
+                                                         float lr_scale, float *__restrict__ rot, const float *__restrict__ grot,
+                                                         float *__restrict__ mrot, float *__restrict__ vrot, float lr_rot, float *__restrict__ opa,
+                                                         const float *__restrict__ gopa, float *__restrict__ mopa, float *__restrict__ vopa,
+                                                         float lr_opac, AdamK k)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float m = mpos[3 * i + c], v = vpos[3 * i + c];
+        pos[3 * i + c] = adam_vec3_elem(pos[3 * i + c], gpos[3 * i + c], m, v, lr_pos, k);
+        mpos[3 * i + c] = m; vpos[3 * i + c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = gscl[3 * i + c], s = scl[3 * i + c];
+        const float m = k.beta1 * mscl[3 * i + c] + k.omb1 * g;
+        const float v = k.beta2 * vscl[3 * i + c] + k.omb2 * (g * g);
+        mscl[3 * i + c] = m; vscl[3 * i + c] = v;
+        const float mc = m / k.bc1, vc = v / k.bc2;
+        const float denom = sqrtf(vc) + k.eps;
+        const float update = lr_scale * (mc / (denom + 1e-9f)); // scale_update = lr * div_element(...)   (optimizer.py:70)
+        scl[3 * i + c] = fmaxf(s - update, 0.001f);
+    }
+    {
+        const float4 g = *reinterpret_cast<const float4 *>(grot + 4 * i);
+        float4 m = *reinterpret_cast<float4 *>(mrot + 4 * i), v = *reinterpret_cast<float4 *>(vrot + 4 * i);
+        float4 q = *reinterpret_cast<float4 *>(rot + 4 * i);
+        float *gm[4] = {&m.x, &m.y, &m.z, &m.w}, *gv[4] = {&v.x, &v.y, &v.z, &v.w}, *gq[4] = {&q.x, &q.y, &q.z, &q.w};
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *gm[c] = k.beta1 * *gm[c] + k.omb1 * gg[c];
+            *gv[c] = k.beta2 * *gv[c] + k.omb2 * (gg[c] * gg[c]);
+            const float mc = *gm[c] / k.bc1, vc = *gv[c] / k.bc2;
+            const float denom = sqrtf(vc) + k.eps;
+            *gq[c] = *gq[c] - lr_rot * mc / denom; // (lr * m_hat) / denom, optimizer.py:96-101
+        }
+        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (len > 0.0f) q = make_float4(q.x / len, q.y / len, q.z / len, q.w / len);
+        *reinterpret_cast<float4 *>(mrot + 4 * i) = m;
+        *reinterpret_cast<float4 *>(vrot + 4 * i) = v;
+        *reinterpret_cast<float4 *>(rot + 4 * i) = q;
+    }
+    {
+        const float g = gopa[i];
+        const float m = k.beta1 * mopa[i] + k.omb1 * g;
+        const float v = k.beta2 * vopa[i] + k.omb2 * (g * g);
+        mopa[i] = m; vopa[i] = v;
+        const float mc = m / k.bc1, vc = v / k.bc2;
+        const float upd = lr_opac * mc / (sqrtf(vc) + k.eps);
+        opa[i] = fmaxf(fminf(opa[i] - upd, 1.0f), 0.0f);
+    }
+}
+
+// SH coefficients: purely element-wise over N*48 floats -> float4, fully coalesced (optimizer.py:128-139)
+__global__ __launch_bounds__(256) void adam_sh_kernel(int64_t n4, float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
+                                                      float4 *__restrict__ v, float lr, AdamK k)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        const float4 gg = g[i];
+        pp.x = adam_vec3_elem(pp.x, gg.x, mm.x, vv.x, lr, k);
+        pp.y = adam_vec3_elem(pp.y, gg.y, mm.y, vv.y, lr, k);
+        pp.z = adam_vec3_elem(pp.z, gg.z, mm.z, vv.z, lr, k);
+        pp.w = adam_vec3_elem(pp.w, gg.w, mm.w, vv.w, lr, k);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+bool group_ok(const GsrAdamGroup &g) { return g.param && g.grad && g.m && g.v; }
+
+} // namespace
+
+extern "C" {
+
+int gsr_l1_loss_grad(const float *rendered, const float *target, float *pixel_grad, float *loss_sum, int32_t W, int32_t H, float l1_weight,
+                     void *stream)
+{
+    if (!rendered || !target || !loss_sum) return GSR_E_NULL;
+    if (W <= 0 || H <= 0) return GSR_E_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return GSR_E_HIP;
+    const int64_t n = (int64_t)W * H * 3;
+    const unsigned blocks = (unsigned)std::min<int64_t>(2048, gsr_div_up(gsr_div_up(n, 4), 256));
+    hipLaunchKernelGGL(l1_loss_grad_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, rendered, target, pixel_grad, loss_sum, n, l1_weight);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
+}
+
+int gsr_adam_update(const GsrAdam *a, void *stream)
+{
+    if (!a) return GSR_E_NULL;
+    if (a->N < 0) return GSR_E_DIMS;
+    if (a->N == 0) return GSR_OK;
+    if (!group_ok(a->pos) || !group_ok(a->scale) || !group_ok(a->rot) || !group_ok(a->opacity) || !group_ok(a->sh)) return GSR_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    AdamK k;
+    k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = a->epsilon;
+    k.omb1 = 1.0f - a->beta1; k.omb2 = 1.0f - a->beta2;
+    // bias corrections in float32 on the host: 1 - pow(beta, float(iteration + 1))   (optimizer.py:47-48)
+    k.bc1 = 1.0f - powf(a->beta1, (float)(a->iteration + 1));
+    k.bc2 = 1.0f - powf(a->beta2, (float)(a->iteration + 1));
+    hipLaunchKernelGGL(adam_small_kernel, dim3((unsigned)gsr_div_up(a->N, 256)), dim3(256), 0, s, a->N, a->pos.param, a->pos.grad, a->pos.m,
+                       a->pos.v, a->pos.lr, a->scale.param, a->scale.grad, a->scale.m, a->scale.v, a->scale.lr, a->rot.param, a->rot.grad,
+                       a->rot.m, a->rot.v, a->rot.lr, a->opacity.param, a->opacity.grad, a->opacity.m, a->opacity.v, a->opacity.lr, k);
+    const int64_t n4 = a->N * 12; // 48 floats per Gaussian
+    const unsigned blocks = (unsigned)std::min<int64_t>(4096, gsr_div_up(n4, 256));
+    hipLaunchKernelGGL(adam_sh_kernel, dim3(blocks), dim3(256), 0, s, n4, (float4 *)a->sh.param, (const float4 *)a->sh.grad, (float4 *)a->sh.m,
+                       (float4 *)a->sh.v, a->sh.lr, k);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
+}
+
+} // extern "C"

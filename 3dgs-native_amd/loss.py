@@ -1,0 +1,39 @@
+"""
+Loss step between forward and backward: the reference's `l1_loss` and
+`compute_image_gradients` (reference loss.py:148-176, :217-244) on the GPU, in one pass over the image.
+As in the reference, `lambda_dssim` only scales the L1 gradient; the SSIM gradient is a TODO there
+(loss.py:243) and is not invented here.
+"""
+import torch
+
+from . import _host, _lib
+
+
+def l1_loss_and_gradients(rendered, target, lambda_dssim=0.0, want_grad=True):
+    """One kernel: returns (loss_sum device tensor [1] = sum |rendered - target|, pixel_grad (H,W,3) or None).
+    mean L1 = loss_sum / (H*W*3); pixel_grad = (1-lambda_dssim)/(H*W*3) * sign(rendered - target)."""
+    L = _lib.lib()
+    dev = _host.device_of(rendered, target)
+    r = _host.to_dev(rendered, torch.float32, dev)
+    H, W = int(r.shape[0]), int(r.shape[1])
+    r = r.reshape(H, W, 3)
+    t = _host.to_dev(target, torch.float32, dev, (H, W, 3))   # alpha already dropped by the caller (train.py:323-334)
+    grad = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if want_grad else None
+    loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+    l1_weight = (1.0 - float(lambda_dssim)) / (H * W * 3.0)
+    with torch.cuda.device(dev):
+        _lib.check(L.gsr_l1_loss_grad(_host.ptr(r), _host.ptr(t), _host.ptr(grad), _host.ptr(loss_sum), W, H, l1_weight,
+                                      _host.stream_ptr(dev)))
+    return loss_sum, grad
+
+
+def l1_loss(rendered, target):
+    """Mean absolute error as a Python float (reference loss.py:148-176; synchronises, as the reference does)."""
+    r = rendered
+    s, _ = l1_loss_and_gradients(rendered, target, want_grad=False)
+    return float(s.item()) / (int(r.shape[0]) * int(r.shape[1]) * 3)
+
+
+def compute_image_gradients(rendered, target, lambda_dssim=0.2):
+    """dL/dpixels for backward() (reference loss.py:217-244)."""
+    return l1_loss_and_gradients(rendered, target, lambda_dssim)[1]

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""
+Counterpart of the reference's training iteration (train.py:920-1066) on the
+MI355X: per step each rank renders its views, forms the L1 loss and pixel gradient, runs backward, all-reduces
+the 59-float gradient arena (one RCCL collective), and applies the fused Adam update -- everything on the GPU,
+parameters resident, no per-iteration host upload.  Densification / pruning / PLY export (row f4) are not
+part of this build.
+
+Targets: with --dataset <NeRF-synthetic dir> the train split (transforms_train.json + PNGs, alpha dropped as
+train.py:323-334) is used; without it, targets are renders of a hidden seeded scene from orbiting cameras.
+
+    python examples/train.py --iterations 200 --gaussians 20000
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train.py --views-per-step 8
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gsr = importlib.import_module("3dgs-native_amd")
+
+
+def load_nerf(path, max_views):
+    from PIL import Image
+    with open(os.path.join(path, "transforms_train.json")) as f:
+        tf = json.load(f)
+    cams, targets = [], []
+    for fr in tf["frames"][:max_views]:
+        img = np.asarray(Image.open(os.path.join(path, fr["file_path"] + ".png")), dtype=np.float32) / 255.0
+        targets.append(img[:, :, :3].copy())
+        cams.append(gsr.cameras.nerf_camera(fr["transform_matrix"], img.shape[1], img.shape[0], tf["camera_angle_x"]))
+    return cams, targets
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", default=None)
+    ap.add_argument("--iterations", type=int, default=100)
+    ap.add_argument("--gaussians", type=int, default=5000)      # reference default (config.py:31)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--views-per-step", type=int, default=1)
+    ap.add_argument("--size", type=int, default=400)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    rank = 0
+    if world > 1:
+        rank, world = gsr.dist.init_from_env(device=dev)
+
+    bg = np.zeros(3, np.float32)
+    if args.dataset:
+        cams, targets = load_nerf(args.dataset, args.views)
+        targets = [torch.as_tensor(t).to(dev) for t in targets]
+    else:
+        cams = [gsr.cameras.nerf_camera(gsr.scenes.orbit_pose(k, args.views), args.size, args.size, gsr.scenes.LEGO_CAMERA_ANGLE_X)
+                for k in range(args.views)]
+        hidden = gsr.scenes.synthetic_scene(args.gaussians, 0.05, 0.5, seed=7)
+        targets = []
+        for c in cams:
+            img, _, _ = gsr.render_gaussians(background=bg, means3D=hidden["means"], opacity=hidden["opacities"], scales=hidden["scales"],
+                                             rotations=hidden["rotations"], viewmatrix=c["world_to_camera"], projmatrix=c["full_proj_matrix"],
+                                             tan_fovx=c["tan_fovx"], tan_fovy=c["tan_fovy"], image_height=c["height"], image_width=c["width"],
+                                             sh=hidden["shs"], degree=3, campos=c["camera_center"])
+            targets.append(img)
+
+    init = gsr.scenes.synthetic_scene(args.gaussians, 0.05, 0.5, seed=8)    # same on every rank (replicated parameters)
+    t = lambda a, shape: torch.as_tensor(np.ascontiguousarray(a, np.float32)).reshape(shape).to(dev)
+    n = args.gaussians
+    P = {"positions": t(init["means"], (n, 3)), "scales": t(init["scales"], (n, 3)), "rotations": t(init["rotations"], (n, 4)),
+         "opacities": t(init["opacities"], (n,)), "shs": t(init["shs"], (n * 16, 3))}
+    M, V = gsr.optimizer.make_state(P)
+    sched = {k: gsr.scheduler.LRScheduler(lr) for k, lr in gsr.optimizer.DEFAULT_LR.items()}
+    rng = np.random.default_rng(0)                                          # same stream on every rank -> same view batch
+    for it in range(args.iterations):
+        batch = rng.choice(len(cams), size=args.views_per_step, replace=False)
+        mine = [int(batch[i]) for i in gsr.dist.views_for_rank(len(batch), rank, world)]
+        arena, loss_acc = None, torch.zeros(1, device=dev)
+        for v in mine:
+            c = cams[v]
+            kw = dict(background=bg, means3D=P["positions"], opacity=P["opacities"], scales=P["scales"], rotations=P["rotations"],
+                      viewmatrix=c["world_to_camera"], projmatrix=c["full_proj_matrix"], tan_fovx=c["tan_fovx"], tan_fovy=c["tan_fovy"],
+                      image_height=c["height"], image_width=c["width"], sh=P["shs"], degree=3, campos=c["camera_center"])
+            img, _, buf = gsr.render_gaussians(**kw)
+            loss_sum, dpix = gsr.loss.l1_loss_and_gradients(img, targets[v])
+            loss_acc += loss_sum / (c["height"] * c["width"] * 3)
+            g = gsr.backward(background=bg, means3D=P["positions"], dL_dpixels=dpix, opacity=P["opacities"], shs=P["shs"], scales=P["scales"],
+                             rotations=P["rotations"], viewmatrix=kw["viewmatrix"], projmatrix=kw["projmatrix"], tan_fovx=kw["tan_fovx"],
+                             tan_fovy=kw["tan_fovy"], image_height=c["height"], image_width=c["width"], campos=kw["campos"],
+                             radii=buf["radii"], means2D=buf["points_xy_image"], conic_opacity=buf["conic_opacity"], rgb=buf["colors"],
+                             cov3Ds=buf["cov3Ds"], clamped=buf["clamped_state"], binning_buffer={"point_list": buf["point_list"]},
+                             img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]})
+            arena = g["_arena"] if arena is None else arena.add_(g["_arena"])
+        if arena is None:
+            arena = torch.zeros(gsr.dist.ARENA_FLOATS * n, device=dev)
+        arena.mul_(1.0 / max(1, len(batch)) * world)                        # mean over the batch after the /world below
+        gsr.dist.reduce_gradients(arena, world, average=True)
+        grads = gsr.dist.arena_views(arena, n)
+        lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}
+        gsr.optimizer.adam_update(P, gsr.optimizer.grads_from_backward(grads), M, V, lrs, iteration=it)
+        if rank == 0 and (it % 10 == 0 or it == args.iterations - 1):
+            print(f"iter {it:5d}  loss {float(loss_acc.item()) / max(1, len(mine)):.6f}")
+
+
+if __name__ == "__main__":
+    main()

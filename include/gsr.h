@@ -155,6 +155,37 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
                  const GsrBinning *binning, const GsrImage *image, const float *dL_dpixels,
                  const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- "next" rows of SURVEY.md section 8(f): the steps either side of the rasterizer in a training iteration ----
+ *
+ * f2  L1 loss + pixel gradient (reference loss.py: l1_loss :148-176 -> l1_loss_kernel :12-31;
+ *     compute_image_gradients :217-244 -> backprop_l1_pixel_gradients :122-146).  One pass:
+ *       *loss_sum   = sum over pixels and channels of |rendered - target|   (device float, overwritten)
+ *       pixel_grad  = l1_weight * sign(rendered - target), sign(0) = +1 as wp.sign   (may be NULL)
+ *     The caller divides loss_sum by W*H*3 (loss.py:174) and passes l1_weight = (1-lambda_dssim)/(H*W*3). */
+int gsr_l1_loss_grad(const float *rendered, const float *target, float *pixel_grad, float *loss_sum, int32_t W, int32_t H,
+                     float l1_weight, void *stream);
+
+/* f3  Fused Adam step with the reference's clamps (reference optimizer.py:7-139, launched at train.py:750-794):
+ *     scale >= 1e-3, quaternion renormalised, opacity clamped to [0,1], +1e-9 in the vec3 divisions
+ *     (utils/wp_utils.py:15-20).  grad pointers may be the slices of the backward's gradient arena. */
+typedef struct GsrAdamGroup {
+    float *param;      /* updated in place */
+    const float *grad;
+    float *m, *v;      /* first / second moments, updated in place */
+    float lr;
+} GsrAdamGroup;
+typedef struct GsrAdam {
+    int64_t N;
+    GsrAdamGroup pos;     /* [N*3] */
+    GsrAdamGroup scale;   /* [N*3] */
+    GsrAdamGroup rot;     /* [N*4] */
+    GsrAdamGroup opacity; /* [N] */
+    GsrAdamGroup sh;      /* [N*16*3] */
+    float beta1, beta2, epsilon;
+    int32_t iteration;    /* 0-based; bias correction uses iteration + 1 (optimizer.py:47-48) */
+} GsrAdam;
+int gsr_adam_update(const GsrAdam *adam, void *stream);
+
 /* ---- profiling aid (the only process-wide state in the library; not thread-safe) ----------------
  * With timing enabled every stage boundary of the three entry points records a hipEvent on the
  * caller's stream (about 1 us each); up to `max_steps` forward+backward pairs are kept.

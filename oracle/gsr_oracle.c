@@ -617,3 +617,88 @@ void gsro_cov3d_backward(int N, const float *scales, const float *rots, const in
         dL_drots[4 * idx] = dL_dx; dL_drots[4 * idx + 1] = dL_dy; dL_drots[4 * idx + 2] = dL_dz; dL_drots[4 * idx + 3] = dL_dr;
     }
 }
+
+/* ===================== "next" rows f2 / f3 ===================== */
+
+/* loss.py:12-31 (l1_loss_kernel) -- launch dim=(width,height): i = x outer, j = y fastest (A7); float
+ * accumulation in that order.  Returns the raw sum; the caller divides by W*H*3 (loss.py:174). */
+float gsro_l1_loss_sum(int W, int H, const float *rendered, const float *target)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < W; ++i)
+        for (int j = 0; j < H; ++j) {
+            const float *r = rendered + 3 * ((size_t)j * W + i), *t = target + 3 * ((size_t)j * W + i);
+            float d0 = fabsf(r[0] - t[0]), d1 = fabsf(r[1] - t[1]), d2 = fabsf(r[2] - t[2]);
+            float l1 = d0 + d1 + d2;
+            acc += l1;
+        }
+    return acc;
+}
+
+/* loss.py:122-146 (backprop_l1_pixel_gradients); wp.sign(x) = -1 if x < 0 else +1 (assumption A9). */
+void gsro_l1_pixel_grad(int W, int H, const float *rendered, const float *target, float l1_weight, float *pixel_grad)
+{
+    for (size_t k = 0; k < (size_t)W * H * 3; ++k) {
+        float d = rendered[k] - target[k];
+        pixel_grad[k] = l1_weight * (d < 0.0f ? -1.0f : 1.0f);
+    }
+}
+
+/* optimizer.py:7-139 (adam_update). */
+void gsro_adam_update(int N, const float *gpos, const float *gscl, const float *grot, const float *gopa, const float *gsh,
+                      float lr_pos, float lr_scale, float lr_rot, float lr_opac, float lr_sh, float beta1, float beta2,
+                      float epsilon, int iteration, float *pos, float *scl, float *rot, float *opa, float *sh, float *mpos,
+                      float *mscl, float *mrot, float *mopa, float *msh, float *vpos, float *vscl, float *vrot, float *vopa,
+                      float *vsh)
+{
+    const float bc1 = 1.0f - powf(beta1, (float)(iteration + 1));
+    const float bc2 = 1.0f - powf(beta2, (float)(iteration + 1));
+    const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    for (int i = 0; i < N; ++i) {
+        for (int c = 0; c < 3; ++c) { /* positions :51-58 */
+            int k = 3 * i + c;
+            mpos[k] = beta1 * mpos[k] + omb1 * gpos[k];
+            vpos[k] = beta2 * vpos[k] + omb2 * (gpos[k] * gpos[k]);
+            float mc = mpos[k] / bc1, vc = vpos[k] / bc2;
+            float den = sqrtf(vc) + epsilon;
+            pos[k] = pos[k] - lr_pos * (mc / (den + 1e-9f));
+        }
+        for (int c = 0; c < 3; ++c) { /* scales :61-75 */
+            int k = 3 * i + c;
+            mscl[k] = beta1 * mscl[k] + omb1 * gscl[k];
+            vscl[k] = beta2 * vscl[k] + omb2 * (gscl[k] * gscl[k]);
+            float mc = mscl[k] / bc1, vc = vscl[k] / bc2;
+            float den = sqrtf(vc) + epsilon;
+            float upd = lr_scale * (mc / (den + 1e-9f));
+            scl[k] = fmaxf_(scl[k] - upd, 0.001f);
+        }
+        for (int c = 0; c < 4; ++c) { /* rotations :78-101 */
+            int k = 4 * i + c;
+            mrot[k] = beta1 * mrot[k] + omb1 * grot[k];
+            vrot[k] = beta2 * vrot[k] + omb2 * (grot[k] * grot[k]);
+            float mc = mrot[k] / bc1, vc = vrot[k] / bc2;
+            float den = sqrtf(vc) + epsilon;
+            rot[k] = rot[k] - lr_rot * mc / den;
+        }
+        { /* :103-115 */
+            float *q = rot + 4 * i;
+            float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            if (len > 0.0f) { q[0] = q[0] / len; q[1] = q[1] / len; q[2] = q[2] / len; q[3] = q[3] / len; }
+        }
+        { /* opacity :118-126 */
+            mopa[i] = beta1 * mopa[i] + omb1 * gopa[i];
+            vopa[i] = beta2 * vopa[i] + omb2 * (gopa[i] * gopa[i]);
+            float mc = mopa[i] / bc1, vc = vopa[i] / bc2;
+            float upd = lr_opac * mc / (sqrtf(vc) + epsilon);
+            opa[i] = fmaxf_(fminf_(opa[i] - upd, 1.0f), 0.0f);
+        }
+        for (int j = 0; j < 48; ++j) { /* SH :128-139 */
+            size_t k = (size_t)i * 48 + j;
+            msh[k] = beta1 * msh[k] + omb1 * gsh[k];
+            vsh[k] = beta2 * vsh[k] + omb2 * (gsh[k] * gsh[k]);
+            float mc = msh[k] / bc1, vc = vsh[k] / bc2;
+            float den = sqrtf(vc) + epsilon;
+            sh[k] = sh[k] - lr_sh * (mc / (den + 1e-9f));
+        }
+    }
+}

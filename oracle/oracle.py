@@ -38,8 +38,9 @@ def lib():
         for name in ("gsro_preprocess", "gsro_prefix_sum", "gsro_duplicate_with_keys", "gsro_sort_pairs",
                      "gsro_identify_tile_ranges", "gsro_render_rows", "gsro_render_backward_rows",
                      "gsro_cov2d_backward", "gsro_projection_backward", "gsro_sh_backward",
-                     "gsro_cov3d_backward"):
+                     "gsro_cov3d_backward", "gsro_l1_pixel_grad", "gsro_adam_update"):
             getattr(_LIB, name).restype = None
+        _LIB.gsro_l1_loss_sum.restype = C.c_float
     return _LIB
 
 
@@ -203,3 +204,37 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
         "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,
         "dL_dcov3D": dL_dcov3D_ret, "_dL_dcov3D_local": dL_dcov3D,
     }
+
+
+# ---- "next" rows f2 / f3 ----
+def l1_loss(rendered, target):
+    """Restates loss.py:148-176: serial float32 sum (x outer, y fastest) / (W*H*3)."""
+    r, t = _f32(rendered), _f32(target)
+    H, W = r.shape[0], r.shape[1]
+    s = lib().gsro_l1_loss_sum(C.c_int(W), C.c_int(H), _f(r), _f(t))
+    return float(s) / (W * H * 3)
+
+
+def compute_image_gradients(rendered, target, lambda_dssim=0.2):
+    """Restates loss.py:217-244."""
+    r, t = _f32(rendered), _f32(target)
+    H, W = r.shape[0], r.shape[1]
+    g = np.zeros((H, W, 3), np.float32)
+    l1_weight = (1.0 - lambda_dssim) / (H * W * 3.0)
+    lib().gsro_l1_pixel_grad(C.c_int(W), C.c_int(H), _f(r), _f(t), C.c_float(l1_weight), _f(g))
+    return g
+
+
+def adam_update(params, grads, m, v, lrs, beta1=0.9, beta2=0.999, epsilon=1e-8, iteration=0):
+    """Restates optimizer.py:7-139 on numpy float32 arrays (updated in place). Keys: positions, scales,
+    rotations, opacities, shs."""
+    n = params["positions"].shape[0]
+    K = ("positions", "scales", "rotations", "opacities", "shs")
+    for d in (params, grads, m, v):
+        for k in K:
+            assert d[k].dtype == np.float32 and d[k].flags["C_CONTIGUOUS"]
+    lib().gsro_adam_update(C.c_int(n), *[_f(grads[k]) for k in K],
+                           C.c_float(lrs["positions"]), C.c_float(lrs["scales"]), C.c_float(lrs["rotations"]),
+                           C.c_float(lrs["opacities"]), C.c_float(lrs["shs"]), C.c_float(beta1), C.c_float(beta2),
+                           C.c_float(epsilon), C.c_int(iteration), *[_f(params[k]) for k in K], *[_f(m[k]) for k in K],
+                           *[_f(v[k]) for k in K])

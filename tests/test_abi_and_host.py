@@ -22,7 +22,7 @@ def libpath():
 
 def test_every_declared_symbol_is_exported(libpath):
     hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
-    declared = set(re.findall(r"\b(gsr_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", hdr))
     assert {"gsr_forward_count", "gsr_forward_render", "gsr_backward", "gsr_strerror"} <= declared
     lib = C.CDLL(libpath)
     for name in sorted(declared):
