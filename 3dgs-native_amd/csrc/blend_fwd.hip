@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int pix_x = tile_x * 16 + (wv & 1) * 8 + (lane & 7);
     const int pix_y = tile_y * 16 + (wv >> 1) * 8 + (lane >> 3);
-    const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+    float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+    asm volatile("" : "+v"(pixf_x), "+v"(pixf_y)); // keep the converted coordinates in registers (hipcc re-converts them per entry otherwise)
     const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
     const int mybit = 1 << wv;
 
@@ -111,44 +112,53 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
 
         if (__all(done)) continue; // this wave has nothing left; keep serving the barriers
 
-        // each wave walks only the entries whose mask has its bit: 64 mask words -> one ballot -> scalar bit loop
-        bool stop = false;
-        for (int g = 0; g < cnt && !stop; g += 64) {
+        // each wave walks only the entries whose mask has its bit: 64 mask words -> one ballot -> scalar bit loop.
+        // Two register sets alternate so the LDS broadcast reads of the next live entry are in flight while the
+        // current one is blended (no register shuffling); saturation of the whole wave is re-checked once per
+        // 64-entry group, not per entry.
+#define GSR_BLEND(A, B, C, J)                                                                                                  \
+    {                                                                                                                         \
+        const float dx = A.x - pixf_x, dy = A.y - pixf_y;                                                                     \
+        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                                          \
+        const float alpha = fminf(0.99f, B.y * fast_exp(power));                                                              \
+        const float test_T = T * (1.0f - alpha);                                                                              \
+        const bool live = !done && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));                                             \
+        const bool sat = live && (test_T < 0.0001f);                                                                          \
+        done = done || sat;                                                                                                   \
+        if (live && !sat) {                                                                                                   \
+            cr += B.z * alpha * T;                                                                                            \
+            cg += B.w * alpha * T;                                                                                            \
+            cb += C.x * alpha * T;                                                                                            \
+            cd += C.y * alpha * T;                                                                                            \
+            T = test_T;                                                                                                       \
+            last = base - start + (J) + 1;                                                                                    \
+        }                                                                                                                     \
+    }
+        for (int g = 0; g < cnt; g += 64) {
             const int mv = (g + lane < cnt) ? s_mask[g + lane] : 0;
             unsigned long long bits = __ballot((mv & mybit) != 0);
             if (!bits) continue;
-            int j = g + __builtin_ctzll(bits);
+            int j0 = g + __builtin_ctzll(bits);
             bits &= bits - 1;
-            float4 a = s_a[j], b = s_b[j];
-            float2 c = s_c[j];
+            float4 a0 = s_a[j0], b0 = s_b[j0];
+            float2 c0 = s_c[j0];
             for (;;) {
-                // LDS reads of the next live entry are issued before this one is blended
-                const int jn = bits ? g + __builtin_ctzll(bits) : j;
-                const float4 a2 = s_a[jn], b2 = s_b[jn];
-                const float2 c2 = s_c[jn];
-                const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, b.y * fast_exp(power));
-                const float test_T = T * (1.0f - alpha);
-                const bool live = !done && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-                const bool sat = live && (test_T < 0.0001f);
-                done = done || sat;
-                if (live && !sat) {
-                    cr += b.z * alpha * T;
-                    cg += b.w * alpha * T;
-                    cb += c.x * alpha * T;
-                    cd += c.y * alpha * T;
-                    T = test_T;
-                    last = base - start + j + 1;
-                }
-                if (__any(sat)) { // wave-uniform: only re-check saturation when some lane just saturated
-                    if (__all(done)) { stop = true; break; }
-                }
-                if (!bits) break;
-                bits &= bits - 1;
-                j = jn; a = a2; b = b2; c = c2;
+                int j1 = j0;
+                const bool more1 = bits != 0;
+                if (more1) { j1 = g + __builtin_ctzll(bits); bits &= bits - 1; }
+                const float4 a1 = s_a[j1], b1 = s_b[j1];
+                const float2 c1 = s_c[j1];
+                GSR_BLEND(a0, b0, c0, j0);
+                if (!more1) break;
+                const bool more0 = bits != 0;
+                if (more0) { j0 = g + __builtin_ctzll(bits); bits &= bits - 1; }
+                a0 = s_a[j0]; b0 = s_b[j0]; c0 = s_c[j0];
+                GSR_BLEND(a1, b1, c1, j1);
+                if (!more0) break;
             }
+            if (__all(done)) break; // the wave's 64 pixels are saturated: nothing later in the list can contribute
         }
+#undef GSR_BLEND
     }
 
     if (pix_x < W && pix_y < H) {
