@@ -144,9 +144,6 @@ void read_tuning()
     static bool done = false;
     if (done) return;
     done = true;
-    if (const char *e = getenv("GSR_BLEND_P")) gsr_blend_p_override = atoi(e);
-    if (const char *e = getenv("GSR_BWD_P")) gsr_bwd_p_override = atoi(e);
-    if (const char *e = getenv("GSR_BWD_MODE")) gsr_bwd_mode = atoi(e);
     if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e);
     if (const char *e = getenv("GSR_BWD_BLOCK")) gsr_bwd_block = atoi(e);
 }
@@ -311,10 +308,7 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
         records = bw.rec;
     }
     mark(st, 11, s);
-    if (D > 0) {
-        if (gsr_bwd_mode == 1) HIP_TRY(gsr_launch_blend_backward(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
-        else HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
-    }
+    if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
     mark(st, 12, s);
     HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));
     mark(st, 13, s);

@@ -6,7 +6,7 @@
 // list ENTRY and the wave walks the pixels, so the nine gradients of an entry accumulate in that
 // lane's registers with no cross-lane reduction at all; what crosses lanes instead is the per-pixel
 // recurrence over entries, and that is two wave-wide DPP scans per pixel:
-//     P_k = prod_{deeper j <= k} (1 - alpha_j)        ->  T_k = T_final / P_k          (backward.py:658)
+//     R_k = prod_{deeper j <= k} 1/(1 - alpha_j)      ->  T_k = T_final * R_k          (backward.py:658)
 //     Q_k = sum_{deeper j <  k} alpha_j T_j (c_j . dL_dpixel)  ( = T_k (1-alpha_k) accum_rec . dL_dpixel, :667-671)
 // so that dL_dalpha_k = T_k (c_k . dL_dpixel) - (Q_k + T_final bg . dL_dpixel) / (1 - alpha_k)   (:671-680).
 // One single-wave workgroup per 8x4 pixel block (8 per tile, 20 000 at 800x800; 8x8 and 4x4 are also
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     constexpr int NBX = 16 / BW;
     __shared__ float4 s_pa[NPIX];   // px, py, Tfin, bgdot*Tfin
     __shared__ float4 s_pb[NPIX];   // dpix r,g,b, kept (as int bits)
-    __shared__ float2 s_carry[NPIX]; // P (product of deeper (1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
+    __shared__ float2 s_carry[NPIX]; // R (product of deeper 1/(1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
     __shared__ int2 s_ring[QCAP];   // compacted survivors: (Gaussian id, list index); records are re-gathered (L2 hits)
     __shared__ float s_g[64][9];    // per-entry gradients for the transposed flush (odd stride: no bank conflicts)
     __shared__ int s_id[64];
@@ -218,20 +218,20 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const float G = fast_exp(power);
             const float alpha = fminf(0.99f, b.y * G);
             const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-            const float one_m = 1.0f - alpha;
-            const float m = live ? one_m : 1.0f;
+            const float inv = fast_rcp(1.0f - alpha);    // 1/(1-alpha): scanned as a product, and reused in dL/dalpha
+            const float m = live ? inv : 1.0f;
             const float Pi = wave_scan_mul(m);
-            const float denom = carry.x * Pi;           // product of (1-alpha) over this entry and everything deeper
-            const float T = pa.z * fast_rcp(denom);     // transmittance in front of this entry
+            const float rdenom = carry.x * Pi;          // product of 1/(1-alpha) over this entry and everything deeper
+            const float T = pa.z * rdenom;              // transmittance in front of this entry = T_final / prod(1-alpha)
             const float cd = b.z * pb.x + b.w * pb.y + colb * pb.z;
             const float w = alpha * T;
             const float qv = live ? w * cd : 0.0f;
             const float Qi = wave_scan_add(qv);
-            if (lane == 63) s_carry[q] = make_float2(denom, carry.y + Qi);
+            if (lane == 63) s_carry[q] = make_float2(rdenom, carry.y + Qi);
             if (live) {
                 touched = true;
                 const float Qe = carry.y + (Qi - qv);   // deeper entries only
-                const float dL_dalpha = T * cd - (Qe + pa.w) * fast_rcp(one_m);
+                const float dL_dalpha = T * cd - (Qe + pa.w) * inv;
                 g_c0 += w * pb.x; g_c1 += w * pb.y; g_c2 += w * pb.z;
                 const float gd = G * dL_dalpha;
                 Sop += gd;
@@ -262,7 +262,33 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     }
 }
 
+// Rebuild blend records from the forward's per-Gaussian outputs (backward() receives them as
+// arguments: means2D, conic_opacity, rgb -- reference backward.py:975-980).
+__global__ __launch_bounds__(256) void pack_records_kernel(const float *__restrict__ xy, const float *__restrict__ conic_opacity,
+                                                           const float *__restrict__ rgb, const float *__restrict__ depths,
+                                                           BlendRec *__restrict__ rec, int64_t N)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float2 p = *reinterpret_cast<const float2 *>(xy + 2 * i);
+    const float4 co = *reinterpret_cast<const float4 *>(conic_opacity + 4 * i);
+    const float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+    const float d = depths ? depths[i] : 0.0f;
+    float4 *rp = reinterpret_cast<float4 *>(rec + i);
+    rp[0] = make_float4(p.x, p.y, co.x, co.y);
+    rp[1] = make_float4(co.z, co.w, r, g);
+    rp[2] = make_float4(b, d != 0.0f ? 1.0f / d : 0.0f, 0.0f, 0.0f);
+}
+
 } // namespace
+
+hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s)
+{
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)gsr_div_up(N, 256)), dim3(256), 0, s, g.xy, g.conic_opacity, g.rgb,
+                       g.depths, rec, N);
+    return hipGetLastError();
+}
 
 int gsr_bwd_block = 32;
 int gsr_debug_flags = 0; // GSR_DEBUG: bit0 = skip atomics, bit1 = one pixel per bucket (timing ablations only)

@@ -174,8 +174,6 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
 
 } // namespace
 
-int gsr_blend_p_override = 1; // unused since the 8x8-block kernel; kept so GSR_BLEND_P stays harmless
-
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
                                     const GsrImage &img, hipStream_t s)
 {

@@ -75,9 +75,6 @@ struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (
     float f[16];                              // 0..2 dcolor, 3..4 dmean2D, 5..7 dconic(a,b,c), 8 dopacity
 };
 hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s);
-hipError_t gsr_launch_blend_backward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
-                                     const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
-                                     GradRec *acc, hipStream_t s);
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                            const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
                                            GradRec *acc, hipStream_t s);
@@ -85,8 +82,5 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
                                     const GsrGrads &gr, hipStream_t s);
 
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
-extern int gsr_blend_p_override;   // GSR_BLEND_P  : pixels per lane in blend_forward_kernel (1, 2, 4)
-extern int gsr_bwd_p_override;     // GSR_BWD_P    : pixels per lane in the pixel-parallel backward
-extern int gsr_bwd_mode;           // GSR_BWD_MODE : 0 = Gaussian-parallel backward (default), 1 = pixel-parallel
 extern int gsr_debug_flags;        // GSR_DEBUG    : timing ablations (wrong results), never set in production
 extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)

@@ -52,7 +52,7 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *lds4 /* >= 4 ints
 }
 
 // ---------------------------------------------------------------------------------------------
-// device-wide scan: per-wave sums -> single-block scan of the sums -> per-wave rescan with offsets.
+// device-wide scan in two kernels: per-wave sums -> per-wave rescan (each wave first adds up the sums before it).
 // The unit of work is a WAVE owning 1024 consecutive items, walked in 16 rounds of 64 so every load and
 // store is a fully coalesced 256-byte access and no block barrier is needed.  In gather mode (values
 // fetched through the depth-sorted ids, 4-byte random reads) the first kernel parks the gathered value
@@ -85,21 +85,6 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
     if (lane == 0) wave_sums[wid] = s;
 }
 
-// exclusive scan of sums[0..nb) in place, one 256-thread block looping over 256-wide slabs
-__global__ __launch_bounds__(256) void scan_mid_kernel(int32_t *__restrict__ block_sums, int nb)
-{
-    __shared__ int lds[4];
-    int carry = 0;
-    for (int base = 0; base < nb; base += 256) {
-        const int k = base + threadIdx.x;
-        const int v = k < nb ? block_sums[k] : 0;
-        int tot;
-        const int inc = block_incl_scan_256(v, lds, &tot);
-        if (k < nb) block_sums[k] = carry + inc - v;
-        carry += tot;
-    }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
                                                          int32_t *__restrict__ out, int64_t n)
@@ -108,7 +93,11 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t base = wid * SCAN_WAVE_ITEMS;
     if (base >= n) return;
-    int carry = wave_sums[wid];
+    // this wave's offset = sum of the sums of all earlier waves: a few KB read per wave beats a third kernel launch
+    int carry = 0;
+    for (int64_t j = lane; j < wid; j += 64) carry += wave_sums[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) carry += __shfl_xor(carry, d, 64);
 #pragma unroll 4
     for (int r = 0; r < SCAN_ROUNDS; ++r) {
         const int64_t k = base + r * 64 + lane;
@@ -331,11 +320,9 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     const int nb = (nw + 3) / 4;
     if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
-        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nw);
         hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n);
     } else {
         hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
-        hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(256), 0, s, block_tmp, nw);
         hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n);
     }
     return hipGetLastError();
