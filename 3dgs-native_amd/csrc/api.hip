@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "gsr_internal.h"
 
 namespace {
@@ -217,7 +219,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     {
         uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
         for (int pass = 0; pass < 4; ++pass) {
-            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, s));
+            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, s));
             uint64_t *t = src; src = dst; dst = t;
         }
         mark(st, 3, s);
@@ -266,8 +268,12 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     // 4. stable partition by tile id
     uint64_t *tsrc = bw.tile_a, *tdst = bw.tile_b;
     const int tb = tile_bits(tiles);
-    for (int shift = 0; shift < tb; shift += 8) {
-        HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, 32 + shift, s));
+    // ceil(tb/8) passes over the tile-id bits, split as evenly as possible (12 bits -> 6+6, 13 -> 7+6)
+    const int npass = (tb + 7) / 8;
+    for (int pass = 0, shift = 0; pass < npass; ++pass) {
+        const int bits = std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass));
+        HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, 32 + shift, bits, s));
+        shift += bits;
         uint64_t *t = tsrc; tsrc = tdst; tdst = t;
     }
     mark(st, 7, s);

@@ -109,28 +109,29 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// stable radix pass (8-bit digit) on 64-bit items
+// stable radix pass (4..8-bit digit) on 64-bit items
 // ---------------------------------------------------------------------------------------------
 // Chunk = 256 * ITEMS items per block (each wave owns 64*ITEMS consecutive items).  ITEMS = 16 for the big
 // D-item passes (fewer, fatter blocks); ITEMS = 4 when n is small, so the launch still fills the chip.
 
 // block histogram of the digit; hist is digit-major [256][nb]
-template <int RADIX_ITEMS>
+template <int RADIX_ITEMS, int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restrict__ in, int32_t *__restrict__ hist, int64_t n,
                                                          int shift, int nb)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
-    __shared__ int h[256];
-    h[threadIdx.x] = 0;
+    constexpr int RADIX = 1 << BITS;
+    __shared__ int h[RADIX];
+    if (threadIdx.x < RADIX) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * CHUNK;
 #pragma unroll 4
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = base + r * 256 + threadIdx.x;
-        if (k < n) atomicAdd(&h[(int)((in[k] >> shift) & 255)], 1);
+        if (k < n) atomicAdd(&h[(int)((in[k] >> shift) & (RADIX - 1))], 1);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < RADIX) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
 // one block per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum
@@ -150,16 +151,17 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict_
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <int RADIX_ITEMS>
+template <int RADIX_ITEMS, int BITS>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
                                                             int64_t n, int shift, int nb)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
-    __shared__ uint64_t s_items[CHUNK]; // 32 KiB: items reordered by digit
-    __shared__ int s_wcnt[4][256];                 // per-wave digit counts -> per-wave start offsets
-    __shared__ int s_dstart[256];                  // first LDS slot of each digit
-    __shared__ int s_gbase[256];                   // global position of the block's first item of each digit
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint64_t s_items[CHUNK]; // items reordered by digit
+    __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
+    __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
+    __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
     __shared__ int s_tmp[4];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -167,8 +169,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     const int64_t wave_base = block_base + (int64_t)w * 64 * RADIX_ITEMS;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
+    if (tid < RADIX) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s_wcnt[k][tid] = 0;
+        for (int k = 0; k < 4; ++k) s_wcnt[k][tid] = 0;
+    }
     __syncthreads();
 
     // pass 1: rank every item among equal digits of its wave, in index order
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
         const int64_t k = wave_base + r * 64 + lane;
         const bool valid = k < n;
         item[r] = valid ? in[k] : ~0ull;
-        const int d = (int)((item[r] >> shift) & 255);
+        const int d = (int)((item[r] >> shift) & (RADIX - 1));
         unsigned long long peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const unsigned long long m = __ballot((d >> b) & 1);
             peers &= ((d >> b) & 1) ? m : ~m;
         }
@@ -203,19 +207,25 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     // per digit: prefix over the 4 waves, block total, then exclusive scan over digits
     {
         const int d = tid;
+        const bool own = d < RADIX; // thread d owns digit d
         int run = 0;
+        if (own) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = s_wcnt[k][d];
-            s_wcnt[k][d] = run;
-            run += c;
+            for (int k = 0; k < 4; ++k) {
+                const int c = s_wcnt[k][d];
+                s_wcnt[k][d] = run;
+                run += c;
+            }
         }
         int tot;
         const int inc = block_incl_scan_256(run, s_tmp, &tot);
-        s_dstart[d] = inc - run;
         // digit base over the whole array = sum of totals of smaller digits
-        const int tinc = block_incl_scan_256(totals[d], s_tmp, &tot);
-        s_gbase[d] = tinc - totals[d] + hist[(size_t)d * nb + blockIdx.x];
+        const int td = own ? totals[d] : 0;
+        const int tinc = block_incl_scan_256(td, s_tmp, &tot);
+        if (own) {
+            s_dstart[d] = inc - run;
+            s_gbase[d] = tinc - td + hist[(size_t)d * nb + blockIdx.x];
+        }
     }
     __syncthreads();
 
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
         if (k < n) {
-            const int d = (int)((item[r] >> shift) & 255);
+            const int d = (int)((item[r] >> shift) & (RADIX - 1));
             s_items[s_dstart[d] + s_wcnt[w][d] + rank[r]] = item[r];
         }
     }
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
         const int slot = r * 256 + tid;
         if (slot < valid_n) {
             const uint64_t it = s_items[slot];
-            const int d = (int)((it >> shift) & 255);
+            const int d = (int)((it >> shift) & (RADIX - 1));
             out[(int64_t)s_gbase[d] + (slot - s_dstart[d])] = it;
         }
     }
@@ -328,20 +338,36 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
+template <int BITS>
+static void radix_pass_bits(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift, hipStream_t s)
+{
+    constexpr int RADIX = 1 << BITS;
+    if (n <= GSR_RADIX_SMALL_N) {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, totals, nb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    } else {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, totals, nb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    }
+}
+
+// One stable pass on the `bits`-wide digit at `shift` (bits in 4..8).  Ranking costs one ballot per digit bit,
+// so passes use the narrowest digits that cover the key: 6+6 bits for the 12-bit tile ids of an 800x800 image.
+hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits,
                                  hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    if (n <= GSR_RADIX_SMALL_N) {
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
-        hipLaunchKernelGGL(radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, totals, nb);
-        hipLaunchKernelGGL(radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
-    } else {
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
-        hipLaunchKernelGGL(radix_hist_kernel<GSR_RADIX_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, s, hist, totals, nb);
-        hipLaunchKernelGGL(radix_scatter_kernel<GSR_RADIX_CHUNK / 256>, dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+    switch (bits) {
+    case 4: radix_pass_bits<4>(in, out, hist, totals, n, shift, s); break;
+    case 5: radix_pass_bits<5>(in, out, hist, totals, n, shift, s); break;
+    case 6: radix_pass_bits<6>(in, out, hist, totals, n, shift, s); break;
+    case 7: radix_pass_bits<7>(in, out, hist, totals, n, shift, s); break;
+    case 8: radix_pass_bits<8>(in, out, hist, totals, n, shift, s); break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
