@@ -21,14 +21,19 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // wave / block scan helpers (wave64)
 // ---------------------------------------------------------------------------------------------
+// Inclusive scan over the 64 lanes in six fused v_add_u32_dpp steps (row_shr 1,2,4,8, row_bcast 15,31).
+// Lanes whose DPP source is outside the row / whose row is masked are write-disabled and keep their
+// value, which is "add 0".  (ds_bpermute-based __shfl_up costs an LDS round trip per step.)
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
     const int64_t base = wid * SCAN_WAVE_ITEMS;
     if (base >= n) return;
     int s = 0;
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < SCAN_ROUNDS; ++r) {
         const int64_t k = base + r * 64 + lane;
         int v = 0;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
     for (int64_t j = lane; j < wid; j += 64) carry += wave_sums[j];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) carry += __shfl_xor(carry, d, 64);
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < SCAN_ROUNDS; ++r) {
         const int64_t k = base + r * 64 + lane;
         const int v = (k < n) ? (MODE == 0 ? in[k] : out[k]) : 0; // gather mode: the value was parked in out by the first kernel
