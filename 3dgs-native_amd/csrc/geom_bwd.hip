@@ -67,33 +67,35 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
     const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
     float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
-    if (rows_valid > 0 && degree > 0)
-        sh_rows_load(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, lds_wave, lane, rows_valid);
-    __syncthreads();
+    ShRegs sh_regs;
+    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, degree > 0 ? rows_valid : 0);
     float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
 
     const int64_t idx = wave_row0 + lane;
     const bool in_range = idx < N;
+    // phase 1 (while the SH rows are in flight): blend-gradient unpacking, cov2d and projection backward
+    float g_col[3] = {0.f, 0.f, 0.f}, g_m2d[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f};
+    float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
+    float mean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sh_written = 0; // number of leading SH coefficients whose gradient was written into the LDS row
+    bool vis = false;
     if (in_range) {
 
     const float4 *ap = reinterpret_cast<const float4 *>(acc + idx);
     const float4 a0 = ap[0], a1 = ap[1];
     const float a8 = acc[idx].f[8];
-    const float g_col[3] = {a0.x, a0.y, a0.z};
-    const float g_m2d[2] = {a0.w, a1.x};
-    const float g_con[3] = {a1.y, a1.z, a1.w}; // d/da, d/db, d/dc
+    g_col[0] = a0.x; g_col[1] = a0.y; g_col[2] = a0.z;
+    g_m2d[0] = a0.w; g_m2d[1] = a1.x;
+    g_con[0] = a1.y; g_con[1] = a1.z; g_con[2] = a1.w; // d/da, d/db, d/dc
     // API-layout copies of the blend-stage gradients
     dL_dcolor[3 * idx] = g_col[0]; dL_dcolor[3 * idx + 1] = g_col[1]; dL_dcolor[3 * idx + 2] = g_col[2];
     dL_dmean2D[3 * idx] = g_m2d[0]; dL_dmean2D[3 * idx + 1] = g_m2d[1]; dL_dmean2D[3 * idx + 2] = 0.0f;
     *reinterpret_cast<float4 *>(dL_dconic + 4 * idx) = make_float4(g_con[0], g_con[1], 0.0f, g_con[2]);
     dL_dopacity[idx] = a8;
 
-    float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
-    int sh_written = 0; // number of leading SH coefficients whose gradient was written into the LDS row
-
-    if (radii[idx] > 0) {
-        const float mean[3] = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
-        float dcov[6];
+    vis = radii[idx] > 0;
+    if (vis) {
+        mean[0] = means[3 * idx]; mean[1] = means[3 * idx + 1]; mean[2] = means[3 * idx + 2];
         // ---------------- cov2d backward (backward.py:259-435) ----------------
         {
             float c3[6];
@@ -183,6 +185,14 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                 o_mean[k] += (PM(k,0) * m_w - PM(k,3) * mul1) * g_m2d[0] + (PM(k,1) * m_w - PM(k,3) * mul2) * g_m2d[1];
 #undef PM
         }
+    } // vis (phase 1)
+    } // in_range (phase 1)
+
+    // phase 2: the SH rows are parked in LDS (block barrier: must sit outside the divergent code)
+    sh_rows_commit(sh_regs, lds_wave, lane);
+    __syncthreads();
+    if (in_range) {
+    if (vis) {
         // ---------------- SH backward (backward.py:69-255) ----------------
         {
             const float dir_orig[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};

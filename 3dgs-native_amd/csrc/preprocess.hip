@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int32_t *__restrict__ radii, float *__restrict__ xy, float *__restrict__ depths, float *__restrict__ cov3Ds,
     float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
-    uint64_t *__restrict__ depth_item)
+    uint64_t *__restrict__ depth_item, int dbg)
 {
     // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
     const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
     float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
-    if (rows_valid > 0) sh_rows_load(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, lds_wave, lane, rows_valid);
+    ShRegs sh_regs;
+    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, (dbg & 4) ? 0 : rows_valid);
     const int64_t i = min(wave_row0 + lane, N - 1); // tail lanes redo the last Gaussian and store nothing
     const bool in_range = wave_row0 + lane < N;
 
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
     }
 
+    sh_rows_commit(sh_regs, lds_wave, lane);
     __syncthreads(); // SH rows have landed in LDS
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 }
     }
     if (!in_range) return;
+    if (dbg & 8) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
 
     radii[i] = o_radius;
     tiles_touched[i] = o_tiles;
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) { rgb[3 * i + k] = o_rgb[k]; clamped_state[3 * i + k] = o_cl[k]; }
     *reinterpret_cast<float4 *>(conic_opacity + 4 * i) = make_float4(o_con[0], o_con[1], o_con[2], o_con[3]);
+    }
 
     // internal products
     float4 *rp = reinterpret_cast<float4 *>(rec + i);
@@ -235,6 +239,6 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     const unsigned blocks = (unsigned)gsr_div_up(sc.N, threads);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
-                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item);
+                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, gsr_debug_flags);
     return hipGetLastError();
 }

@@ -11,6 +11,29 @@
 #define SH_ROW_F4 13                      // padded row length in float4
 #define SH_WAVE_F4 (64 * SH_ROW_F4)       // LDS float4 per wave
 
+// Split form: issue the 12 coalesced loads early (fetch), do unrelated math, then park them in LDS (commit),
+// so the HBM latency of the 12 KiB hides under that math instead of in front of it.
+struct ShRegs {
+    float4 v[12];
+};
+__device__ __forceinline__ void sh_rows_fetch(const float4 *__restrict__ g4, ShRegs &regs, int lane, int rows_valid)
+{
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int i = k * 64 + lane;
+        regs.v[k] = (i / 12 < rows_valid) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void sh_rows_commit(const ShRegs &regs, float4 *lds_wave, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int i = k * 64 + lane;
+        const int r = i / 12, c = i - r * 12;
+        lds_wave[r * SH_ROW_F4 + c] = regs.v[k];
+    }
+}
+
 // g4: first row of the wave (global, as float4); rows_valid: rows of this wave that exist (<= 64)
 __device__ __forceinline__ void sh_rows_load(const float4 *__restrict__ g4, float4 *lds_wave, int lane, int rows_valid)
 {
