@@ -110,3 +110,34 @@ def test_synthetic_scene_is_seeded(scenes):
     assert a["shs"].shape == (100, 16, 3) and a["rotations"].shape == (100, 4)
     np.testing.assert_allclose(np.linalg.norm(a["rotations"], axis=1), 1.0, atol=1e-6)
     assert a["scales"].min() >= 1e-3
+
+
+def test_argument_validation_needs_no_gpu(libpath):
+    """Bad arguments are rejected before any HIP call, so this runs on a CPU-only box."""
+    _lib = sub("_lib")
+    L = _lib.lib()
+    scene, cam, geom = _lib.GsrScene(), _lib.GsrCamera(), _lib.GsrGeom()
+    D = C.c_int64(-1)
+    assert L.gsr_forward_count(None, C.byref(cam), C.byref(geom), None, 0, C.byref(D), None) == _lib.GSR_E_NULL
+    scene.N, cam.W, cam.H, scene.sh_degree = 10, 0, 16, 3
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), None, 0, C.byref(D), None) == _lib.GSR_E_DIMS
+    cam.W, scene.sh_degree = 16, 4
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), None, 0, C.byref(D), None) == _lib.GSR_E_DIMS
+    scene.sh_degree = 3     # N > 0 with null arrays
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), None, 0, C.byref(D), None) == _lib.GSR_E_NULL
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), None, 0, None, None) == _lib.GSR_E_NULL
+    scene.N = 0             # N == 0 is accepted and yields D = 0 without touching the device
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), None, 0, C.byref(D), None) == _lib.GSR_OK and D.value == 0
+    assert L.gsr_adam_update(None, None) == _lib.GSR_E_NULL
+    assert L.gsr_l1_loss_grad(None, None, None, None, 4, 4, C.c_float(1.0), None) == _lib.GSR_E_NULL
+    a = _lib.GsrAdam()
+    a.N = 0
+    assert L.gsr_adam_update(C.byref(a), None) == _lib.GSR_OK
+
+
+def test_lr_scheduler_matches_the_reference_formula():
+    sch = sub("scheduler").LRScheduler(1e-2, 0.01)
+    assert sch.get_lr(0, 7000) == 1e-2
+    assert abs(sch.get_lr(6999, 7000) - 1e-4) < 1e-12
+    assert abs(sch.get_lr(3500, 7001) - 1e-3) < 1e-9        # geometric midpoint
+    assert sch.get_lr(10 ** 6, 7000) == sch.get_lr(6999, 7000) and sch.get_lr(5, 1) == 1e-2

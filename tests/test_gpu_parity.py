@@ -151,3 +151,30 @@ def test_torch_inputs_stay_on_device(oracle, cameras, scenes):
         kw2[k_kw] = torch.as_tensor(sc[k_np]).cuda()
     got = gsr.render_gaussians(**kw2)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2]["point_list"], ref[2]["point_list"])
+
+
+def test_workspace_and_capacity_errors(cameras, scenes):
+    """Too-small scratch buffers are refused with GSR_E_WORKSPACE (mapped to RuntimeError), not overrun."""
+    import ctypes as C
+    import torch
+    from conftest import sub
+    gsr = pkg()
+    _lib, _host = sub("_lib"), sub("_host")
+    L = _lib.lib()
+    sc = scenes.synthetic_scene(500, 0.05, 0.5, 3)
+    cam = lego_camera(cameras, 0, 64, 64)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    means, scl, rot, op, sh = t(sc["means"]), t(sc["scales"]), t(sc["rotations"]), t(sc["opacities"].reshape(-1)), t(sc["shs"].reshape(-1, 3))
+    scene = _lib.GsrScene(500, _host.ptr(means), _host.ptr(scl), _host.ptr(rot), _host.ptr(op), _host.ptr(sh), 3, 1.0, 1)
+    camera = _host.make_camera(cam["world_to_camera"], cam["full_proj_matrix"], cam["camera_center"], [0, 0, 0], cam["tan_fovx"], cam["tan_fovy"], 64, 64)
+    bufs = [torch.empty(500 * 8, dtype=torch.float32, device=dev) for _ in range(9)]
+    geom = _lib.GsrGeom(*[_host.ptr(b) for b in bufs], None)
+    small = torch.empty(1024, dtype=torch.uint8, device=dev)
+    D = C.c_int64(0)
+    rc = L.gsr_forward_count(C.byref(scene), C.byref(camera), C.byref(geom), _host.ptr(small), small.numel(), C.byref(D), None)
+    assert rc == _lib.GSR_E_WORKSPACE
+    with pytest.raises(RuntimeError):
+        _lib.check(rc)
+    with pytest.raises(ValueError):
+        gsr.render_gaussians(**dict(render_kwargs(sc, cam), sh=sc["shs"][:, :4]))   # not 16 coefficients per Gaussian
