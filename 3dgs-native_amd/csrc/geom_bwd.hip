@@ -67,12 +67,15 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
     const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
     float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
-    ShRegs sh_regs;
-    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, degree > 0 ? rows_valid : 0);
-    float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
-
     const int64_t idx = wave_row0 + lane;
     const bool in_range = idx < N;
+    // only the SH rows of visible Gaussians are read (the radii are known up front here)
+    const int my_radius = in_range ? radii[idx] : 0;
+    const unsigned long long row_mask = (degree > 0) ? __ballot(my_radius > 0) : 0ull;
+    ShRegs sh_regs;
+    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, row_mask);
+    float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
+
     // phase 1 (while the SH rows are in flight): blend-gradient unpacking, cov2d and projection backward
     float g_col[3] = {0.f, 0.f, 0.f}, g_m2d[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f};
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     *reinterpret_cast<float4 *>(dL_dconic + 4 * idx) = make_float4(g_con[0], g_con[1], 0.0f, g_con[2]);
     dL_dopacity[idx] = a8;
 
-    vis = radii[idx] > 0;
+    vis = my_radius > 0;
     if (vis) {
         mean[0] = means[3 * idx]; mean[1] = means[3 * idx + 1]; mean[2] = means[3 * idx + 2];
         // ---------------- cov2d backward (backward.py:259-435) ----------------

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
     float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
     ShRegs sh_regs;
-    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, (dbg & 4) ? 0 : rows_valid);
+    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, (dbg & 4) ? 0ull : sh_rows_all(rows_valid));
     const int64_t i = min(wave_row0 + lane, N - 1); // tail lanes redo the last Gaussian and store nothing
     const bool in_range = wave_row0 + lane < N;
 

@@ -16,14 +16,16 @@
 struct ShRegs {
     float4 v[12];
 };
-__device__ __forceinline__ void sh_rows_fetch(const float4 *__restrict__ g4, ShRegs &regs, int lane, int rows_valid)
+// row_mask: bit r set = row r of the wave is wanted (rows of culled Gaussians are not read at all)
+__device__ __forceinline__ void sh_rows_fetch(const float4 *__restrict__ g4, ShRegs &regs, int lane, unsigned long long row_mask)
 {
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         const int i = k * 64 + lane;
-        regs.v[k] = (i / 12 < rows_valid) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        regs.v[k] = ((row_mask >> (i / 12)) & 1ull) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+__device__ __forceinline__ unsigned long long sh_rows_all(int rows_valid) { return rows_valid >= 64 ? ~0ull : ((1ull << rows_valid) - 1ull); }
 __device__ __forceinline__ void sh_rows_commit(const ShRegs &regs, float4 *lds_wave, int lane)
 {
 #pragma unroll
