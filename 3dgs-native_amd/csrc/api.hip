@@ -219,7 +219,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     {
         uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
         for (int pass = 0; pass < 4; ++pass) {
-            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, s));
+            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, 8, s));
             uint64_t *t = src; src = dst; dst = t;
         }
         mark(st, 3, s);
@@ -262,23 +262,29 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
 
     const int st = g_timer.fwd_step;
     mark(st, 5, s);
-    // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile, id) items
-    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, D, s));
-    mark(st, 6, s);
-    // 4. stable partition by tile id
-    uint64_t *tsrc = bw.tile_a, *tdst = bw.tile_b;
+    // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile << id_shift | id) items.  When the tile
+    //    bits and the id bits fit one 32-bit word (800x800 with 1M Gaussians: 12 + 20) the items are uint32, which
+    //    halves the traffic of the expansion, both partition passes and the range scan.
     const int tb = tile_bits(tiles);
-    // ceil(tb/8) passes over the tile-id bits, split as evenly as possible (12 bits -> 6+6, 13 -> 7+6)
+    int id_bits = 1;
+    while ((1LL << id_bits) < N) ++id_bits;
+    const bool narrow = tb + id_bits <= 32;
+    const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
+    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, s));
+    mark(st, 6, s);
+    // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible
+    //    (12 bits -> 6+6, 13 -> 7+6)
+    void *tsrc = bw.tile_a, *tdst = bw.tile_b;
     const int npass = (tb + 7) / 8;
     for (int pass = 0, shift = 0; pass < npass; ++pass) {
         const int bits = std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass));
-        HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, 32 + shift, bits, s));
+        HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, id_shift + shift, bits, item_bytes, s));
         shift += bits;
-        uint64_t *t = tsrc; tsrc = tdst; tdst = t;
+        void *t = tsrc; tsrc = tdst; tdst = t;
     }
     mark(st, 7, s);
     // 5. point_list + ranges, 6. blend
-    HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, s));
+    HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, id_shift, item_bytes, s));
     mark(st, 8, s);
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, s));
     mark(st, 9, s);

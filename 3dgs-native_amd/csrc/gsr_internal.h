@@ -55,18 +55,19 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
                            int64_t n, int mode, hipStream_t s);
 
-// One stable LSD radix pass on 64-bit items by the `bits`-wide (4..8) digit at `shift`.
+// One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096
 #define GSR_RADIX_SMALL_CHUNK 1024      // chunk used when n <= GSR_RADIX_SMALL_N (more, smaller blocks)
 #define GSR_RADIX_SMALL_N (4 << 20)
 static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_N ? (n + GSR_RADIX_SMALL_CHUNK - 1) / GSR_RADIX_SMALL_CHUNK : (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
-hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *hist /*[256*nb]*/, int32_t *totals /*[256]*/,
-                                 int64_t n, int shift, int bits, hipStream_t s);
+hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[radix*nb]*/, int32_t *totals /*[radix]*/,
+                                 int64_t n, int shift, int bits, int item_bytes, hipStream_t s);
 
-hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect,
-                             uint64_t *tile_items, int64_t n, int grid_x, int64_t D, hipStream_t s);
-hipError_t gsr_launch_ranges(const uint64_t *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D,
-                             hipStream_t s);
+// Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
+hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
+                             int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, hipStream_t s);
+hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift,
+                             int item_bytes, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                     const BlendRec *rec, const GsrImage &img, hipStream_t s);
 

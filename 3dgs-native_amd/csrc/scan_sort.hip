@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 // D-item passes (fewer, fatter blocks); ITEMS = 4 when n is small, so the launch still fills the chip.
 
 // block histogram of the digit; hist is digit-major [256][nb]
-template <int RADIX_ITEMS, int BITS>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t *__restrict__ in, int32_t *__restrict__ hist, int64_t n,
+template <int RADIX_ITEMS, int BITS, typename ItemT>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int64_t n,
                                                          int shift, int nb)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
@@ -156,14 +156,14 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict_
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <int RADIX_ITEMS, int BITS>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+template <int RADIX_ITEMS, int BITS, typename ItemT>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
                                                             int64_t n, int shift, int nb)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
-    __shared__ uint64_t s_items[CHUNK]; // items reordered by digit
+    __shared__ ItemT s_items[CHUNK];    // items reordered by digit
     __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
     __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
     __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
@@ -181,13 +181,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     __syncthreads();
 
     // pass 1: rank every item among equal digits of its wave, in index order
-    uint64_t item[RADIX_ITEMS];
+    ItemT item[RADIX_ITEMS];
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
         const bool valid = k < n;
-        item[r] = valid ? in[k] : ~0ull;
+        item[r] = valid ? in[k] : (ItemT)~(ItemT)0;
         const int d = (int)((item[r] >> shift) & (RADIX - 1));
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int slot = r * 256 + tid;
         if (slot < valid_n) {
-            const uint64_t it = s_items[slot];
+            const ItemT it = s_items[slot];
             const int d = (int)((it >> shift) & (RADIX - 1));
             out[(int64_t)s_gbase[d] + (slot - s_dstart[d])] = it;
         }
@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t *__re
 // [doff[k0], doff[k0+64]) is contiguous.  Lanes walk that range 64 items at a time (fully coalesced
 // 8-byte stores) and find each item's owner by a 6-step binary search over the wave's 64 offsets in
 // LDS, so a Gaussian covering thousands of tiles costs no more per item than one covering four.
+template <typename ItemT>
 __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ doff,
-                                                     const TileRect *__restrict__ rect, uint64_t *__restrict__ tile_items, int64_t n,
-                                                     int grid_x, int64_t D)
+                                                     const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n,
+                                                     int grid_x, int64_t D, int id_shift)
 {
     __shared__ int s_off[4][64];
     __shared__ TileRect s_rect[4][64];
@@ -301,22 +302,23 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
         const int t = j - s_off[w][lo];
         const int wd = (int)r.x1 - (int)r.x0;
         const int y = t / wd, x = t - y * wd; // row-major walk: y outer, x inner (reference forward.py:546-548)
-        tile_items[j] = ((uint64_t)(uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x) << 32) | s_gid[w][lo];
+        tile_items[j] = (ItemT)(((ItemT)(uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x) << id_shift) | (ItemT)s_gid[w][lo]);
     }
 }
 
 // sorted tile items -> point_list + tile ranges (reference forward.py:561-586); ranges pre-zeroed
-__global__ __launch_bounds__(256) void ranges_kernel(const uint64_t *__restrict__ items, int32_t *__restrict__ point_list,
-                                                     int32_t *__restrict__ ranges, int64_t D)
+template <typename ItemT>
+__global__ __launch_bounds__(256) void ranges_kernel(const ItemT *__restrict__ items, int32_t *__restrict__ point_list,
+                                                     int32_t *__restrict__ ranges, int64_t D, int id_shift)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= D) return;
-    const uint64_t it = items[idx];
-    point_list[idx] = (int32_t)(uint32_t)it;
-    const uint32_t cur = (uint32_t)(it >> 32);
+    const ItemT it = items[idx];
+    point_list[idx] = (int32_t)(uint32_t)(it & (((ItemT)1 << id_shift) - 1));
+    const uint32_t cur = (uint32_t)(it >> id_shift);
     if (idx == 0) ranges[2 * cur] = 0;
     else {
-        const uint32_t prev = (uint32_t)(items[idx - 1] >> 32);
+        const uint32_t prev = (uint32_t)(items[idx - 1] >> id_shift);
         if (cur != prev) {
             ranges[2 * prev + 1] = (int32_t)idx;
             ranges[2 * cur] = (int32_t)idx;
@@ -343,52 +345,68 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     return hipGetLastError();
 }
 
-template <int BITS>
-static void radix_pass_bits(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift, hipStream_t s)
+template <int BITS, typename ItemT>
+static void radix_pass_bits(const ItemT *in, ItemT *out, int32_t *hist, int32_t *totals, int64_t n, int shift, hipStream_t s)
 {
     constexpr int RADIX = 1 << BITS;
     if (n <= GSR_RADIX_SMALL_N) {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, totals, nb);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
     } else {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, totals, nb);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
     }
 }
 
-// One stable pass on the `bits`-wide digit at `shift` (bits in 4..8).  Ranking costs one ballot per digit bit,
-// so passes use the narrowest digits that cover the key: 6+6 bits for the 12-bit tile ids of an 800x800 image.
-hipError_t gsr_launch_radix_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits,
-                                 hipStream_t s)
+template <typename ItemT>
+static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, hipStream_t s)
 {
-    if (n <= 0) return hipSuccess;
     switch (bits) {
-    case 4: radix_pass_bits<4>(in, out, hist, totals, n, shift, s); break;
-    case 5: radix_pass_bits<5>(in, out, hist, totals, n, shift, s); break;
-    case 6: radix_pass_bits<6>(in, out, hist, totals, n, shift, s); break;
-    case 7: radix_pass_bits<7>(in, out, hist, totals, n, shift, s); break;
-    case 8: radix_pass_bits<8>(in, out, hist, totals, n, shift, s); break;
+    case 4: radix_pass_bits<4, ItemT>(in, out, hist, totals, n, shift, s); break;
+    case 5: radix_pass_bits<5, ItemT>(in, out, hist, totals, n, shift, s); break;
+    case 6: radix_pass_bits<6, ItemT>(in, out, hist, totals, n, shift, s); break;
+    case 7: radix_pass_bits<7, ItemT>(in, out, hist, totals, n, shift, s); break;
+    case 8: radix_pass_bits<8, ItemT>(in, out, hist, totals, n, shift, s); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, uint64_t *tile_items,
-                             int64_t n, int grid_x, int64_t D, hipStream_t s)
+// One stable pass on the `bits`-wide digit at `shift` (bits in 4..8).  Ranking costs one ballot per digit bit,
+// so passes use the narrowest digits that cover the key: 6+6 bits for the 12-bit tile ids of an 800x800 image.
+// item_bytes: 8 (uint64 items) or 4 (uint32 items: tile id and Gaussian id share one word when they fit).
+hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits,
+                                 int item_bytes, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    if (item_bytes == 4) return radix_pass_any<uint32_t>((const uint32_t *)in, (uint32_t *)out, hist, totals, n, shift, bits, s);
+    return radix_pass_any<uint64_t>((const uint64_t *)in, (uint64_t *)out, hist, totals, n, shift, bits, s);
+}
+
+hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,
+                             int grid_x, int64_t D, int id_shift, int item_bytes, hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)gsr_div_up(n, 256)), dim3(256), 0, s, sorted_depth_items, doff, rect, tile_items,
-                       n, grid_x, D);
+    const dim3 grid((unsigned)gsr_div_up(n, 256));
+    if (item_bytes == 4)
+        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift);
+    else
+        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift);
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_ranges(const uint64_t *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, hipStream_t s)
+hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift, int item_bytes,
+                             hipStream_t s)
 {
     if (D <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)gsr_div_up(D, 256)), dim3(256), 0, s, sorted_tile_items, point_list, ranges, D);
+    const dim3 grid((unsigned)gsr_div_up(D, 256));
+    if (item_bytes == 4)
+        hipLaunchKernelGGL(ranges_kernel<uint32_t>, grid, dim3(256), 0, s, (const uint32_t *)sorted_tile_items, point_list, ranges, D, id_shift);
+    else
+        hipLaunchKernelGGL(ranges_kernel<uint64_t>, grid, dim3(256), 0, s, (const uint64_t *)sorted_tile_items, point_list, ranges, D, id_shift);
     return hipGetLastError();
 }
