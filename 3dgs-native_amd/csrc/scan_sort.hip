@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     __syncthreads();
     if (k0 >= n) return;
     const int begin = s_off[w][0];
-    const int end = (k0 + 64 < n) ? doff[k0 + 64] : (int)D;
+    // never write past the caller's D, even if it under-reports the count gsr_forward_count returned
+    const int end = min((int)D, (k0 + 64 < n) ? doff[k0 + 64] : (int)D);
     for (int j = begin + lane; j < end; j += 64) {
         int lo = 0; // last k with off[k] <= j (zero-count Gaussians share their successor's offset)
 #pragma unroll
