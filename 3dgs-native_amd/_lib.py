@@ -67,6 +67,7 @@ EXPORTS = {
     "gsr_l1_loss_grad": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
     "gsr_adam_update": (C.c_int, [C.POINTER(GsrAdam), vp]),
     "gsr_stage_timing": (C.c_int, [C.c_int, C.c_int]),
+    "gsr_stage_sampling": (C.c_int, [C.c_int]),
     "gsr_stage_times": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
@@ -106,8 +107,11 @@ def check(code):
     raise RuntimeError(f"libgsr_hip: {strerror(code)} (code {code})")
 
 
-def stage_timing(enable, max_steps=256):
+def stage_timing(enable, max_steps=256, every=1):
+    """Record per-stage HIP events on one forward/backward pair in `every` (event records are not free)."""
     check(lib().gsr_stage_timing(1 if enable else 0, int(max_steps)))
+    if enable:
+        check(lib().gsr_stage_sampling(int(every)))
 
 
 def stage_times():

@@ -13,6 +13,20 @@ import torch
 from . import _host, _lib
 
 
+_ZERO_COV = {}
+
+
+def _zeros_cov3d(n, dev):
+    """The reference returns an all-zero dL_dcov3D (backward.py:1119 is never filled); hand out one shared,
+    read-only-by-convention zero tensor per (N, device) instead of clearing 24*N bytes every call."""
+    key = (n, dev.index)
+    t = _ZERO_COV.get(key)
+    if t is None:
+        _ZERO_COV.clear()
+        t = _ZERO_COV[key] = torch.zeros((n, 6), dtype=torch.float32, device=dev)
+    return t
+
+
 def _get(buf, key):
     if buf is None:
         raise NameError(f"backward() needs the forward buffer holding '{key}' (the reference fails the same way, "
@@ -85,6 +99,6 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     return {
         "dL_dmean3D": dL_dmean3D, "dL_dcolor": dL_dcolor, "dL_dshs": dL_dsh, "dL_dopacity": dL_dopacity,
         "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,
-        "dL_dcov3D": torch.zeros((N, 6), dtype=f32, device=dev),
+        "dL_dcov3D": _zeros_cov3d(N, dev),
         "_arena": arena,
     }

@@ -109,7 +109,9 @@ bool geom_ok(const GsrGeom *g)
 // ---- stage timing (profiling aid) ----
 struct StageTimer {
     bool on = false;
-    int max_steps = 0, fwd_step = 0, bwd_step = 0;
+    int max_steps = 0, fwd_step = 0, bwd_step = 0; // recorded (sampled) steps so far
+    int every = 1, fwd_calls = 0, bwd_calls = 0;    // record one call in `every`; event records cost ~3 us each
+    bool fwd_sampled = false;
     hipEvent_t *ev = nullptr; // [max_steps][GSR_NSTAGES + 3]
     static constexpr int PER = GSR_NSTAGES + 3;
     hipEvent_t &at(int step, int k) { return ev[(size_t)step * PER + k]; }
@@ -118,7 +120,7 @@ struct StageTimer {
 // 10..13 backward boundaries
 inline void mark(int step, int slot, hipStream_t s)
 {
-    if (g_timer.on && step < g_timer.max_steps) (void)hipEventRecord(g_timer.at(step, slot), s);
+    if (step >= 0 && step < g_timer.max_steps) (void)hipEventRecord(g_timer.at(step, slot), s);
 }
 
 // Per-device readback slot for D: 4 bytes of pinned host memory + an event, created on first use and
@@ -204,7 +206,8 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     hipStream_t s = (hipStream_t)stream;
     const CamK cam = make_cam(camera);
     const GeomWs ws = gsr_carve_geom(geom_ws, N);
-    const int st = g_timer.fwd_step;
+    g_timer.fwd_sampled = g_timer.on && (g_timer.fwd_calls++ % g_timer.every) == 0;
+    const int st = g_timer.fwd_sampled ? g_timer.fwd_step : -1;
     mark(st, 0, s);
     HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s));
     mark(st, 1, s);
@@ -246,8 +249,8 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const CamK cam = make_cam(camera);
     const size_t P = (size_t)cam.W * cam.H;
     const int tiles = cam.grid_x * cam.grid_y;
-    HIP_TRY(hipMemsetAsync(binning->ranges, 0, sizeof(int32_t) * 2 * tiles, s));
     if (D == 0 || N == 0) { // reference skips the blend: zeros, not background (forward.py:830, quirk Q10)
+        HIP_TRY(hipMemsetAsync(binning->ranges, 0, sizeof(int32_t) * 2 * tiles, s));
         HIP_TRY(hipMemsetAsync(image->image, 0, P * 3 * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(image->inv_depth, 0, P * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(image->final_T, 0, P * sizeof(float), s));
@@ -260,7 +263,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const GeomWs gw = gsr_carve_geom(geom_ws, N);
     const BinWs bw = carve_bin(bin_ws, N, D);
 
-    const int st = g_timer.fwd_step;
+    const int st = g_timer.fwd_sampled ? g_timer.fwd_step : -1;
     mark(st, 5, s);
     // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile << id_shift | id) items.  When the tile
     //    bits and the id bits fit one 32-bit word (800x800 with 1M Gaussians: 12 + 20) the items are uint32, which
@@ -270,7 +273,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     while ((1LL << id_bits) < N) ++id_bits;
     const bool narrow = tb + id_bits <= 32;
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
-    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, s));
+    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, s));
     mark(st, 6, s);
     // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible
     //    (12 bits -> 6+6, 13 -> 7+6)
@@ -288,7 +291,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     mark(st, 8, s);
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, s));
     mark(st, 9, s);
-    if (g_timer.on) ++g_timer.fwd_step;
+    if (g_timer.fwd_sampled) ++g_timer.fwd_step;
     return GSR_OK;
 }
 
@@ -311,7 +314,8 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     hipStream_t s = (hipStream_t)stream;
     const CamK cam = make_cam(camera);
     const BwdWs bw = carve_bwd(ws, N);
-    const int st = g_timer.bwd_step;
+    const bool bwd_sampled = g_timer.on && (g_timer.bwd_calls++ % g_timer.every) == 0;
+    const int st = bwd_sampled ? g_timer.bwd_step : -1;
     mark(st, 10, s);
     HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
     const BlendRec *records = (const BlendRec *)geom->blend_records;
@@ -324,7 +328,7 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     mark(st, 12, s);
     HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));
     mark(st, 13, s);
-    if (g_timer.on) ++g_timer.bwd_step;
+    if (bwd_sampled) ++g_timer.bwd_step;
     return GSR_OK;
 }
 
@@ -336,7 +340,8 @@ int gsr_stage_timing(int enable, int max_steps)
         g_timer.ev = nullptr;
     }
     g_timer.on = false;
-    g_timer.max_steps = g_timer.fwd_step = g_timer.bwd_step = 0;
+    g_timer.max_steps = g_timer.fwd_step = g_timer.bwd_step = g_timer.fwd_calls = g_timer.bwd_calls = 0;
+    g_timer.every = 1;
     if (!enable) return GSR_OK;
     if (max_steps <= 0 || max_steps > 4096) return GSR_E_DIMS;
     g_timer.ev = (hipEvent_t *)calloc((size_t)max_steps * StageTimer::PER, sizeof(hipEvent_t));
@@ -344,6 +349,13 @@ int gsr_stage_timing(int enable, int max_steps)
     for (size_t i = 0; i < (size_t)max_steps * StageTimer::PER; ++i) HIP_TRY(hipEventCreate(&g_timer.ev[i]));
     g_timer.max_steps = max_steps;
     g_timer.on = true;
+    return GSR_OK;
+}
+
+int gsr_stage_sampling(int every)
+{
+    if (every < 1) return GSR_E_DIMS;
+    g_timer.every = every;
     return GSR_OK;
 }
 

@@ -65,7 +65,8 @@ hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[rad
 
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
-                             int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, hipStream_t s);
+                             int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
+                             hipStream_t s);
 hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift,
                              int item_bytes, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,

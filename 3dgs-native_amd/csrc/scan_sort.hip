@@ -269,8 +269,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
 template <typename ItemT>
 __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ doff,
                                                      const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n,
-                                                     int grid_x, int64_t D, int id_shift)
+                                                     int grid_x, int64_t D, int id_shift, int32_t *__restrict__ ranges, int ranges_n)
 {
+    // also clears the tile ranges (filled later by ranges_kernel; untouched tiles must read (0,0)): saves a memset launch
+    for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < ranges_n; z += (int64_t)gridDim.x * 256) ranges[z] = 0;
     __shared__ int s_off[4][64];
     __shared__ TileRect s_rect[4][64];
     __shared__ uint32_t s_gid[4][64];
@@ -389,14 +391,14 @@ hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32
 }
 
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,
-                             int grid_x, int64_t D, int id_shift, int item_bytes, hipStream_t s)
+                             int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n, hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
     const dim3 grid((unsigned)gsr_div_up(n, 256));
     if (item_bytes == 4)
-        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift);
+        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n);
     else
-        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift);
+        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n);
     return hipGetLastError();
 }
 

@@ -188,7 +188,8 @@ int gsr_adam_update(const GsrAdam *adam, void *stream);
 
 /* ---- profiling aid (the only process-wide state in the library; not thread-safe) ----------------
  * With timing enabled every stage boundary of the three entry points records a hipEvent on the
- * caller's stream (about 1 us each); up to `max_steps` forward+backward pairs are kept.
+ * caller's stream (about 3 us each, and kernels no longer dispatch back to back across a record: ~6 % of a
+ * C3 step if every step is recorded, so bench.py samples one step in five); up to `max_steps` pairs are kept.
  * gsr_stage_times() -- call it after synchronising the stream -- returns the average milliseconds per
  * stage over the steps recorded since enabling, and clears the record. */
 enum {
@@ -207,6 +208,7 @@ enum {
     GSR_NSTAGES
 };
 int gsr_stage_timing(int enable, int max_steps);
+int gsr_stage_sampling(int every); /* after enabling: record only one forward/backward pair in `every` (default 1) */
 int gsr_stage_times(float *avg_ms /* [GSR_NSTAGES] host */, int *steps /* host */);
 
 #ifdef __cplusplus
