@@ -137,7 +137,7 @@ Readback *readback_slot()
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     Readback &r = slots[dev];
     if (!r.pinned) {
-        if (hipHostMalloc((void **)&r.pinned, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipHostMalloc((void **)&r.pinned, 64, hipHostMallocMapped) != hipSuccess) return nullptr; // device-writable
         if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
     return &r;
@@ -211,11 +211,11 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     mark(st, 0, s);
     HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s));
     mark(st, 1, s);
-    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, s));
-    mark(st, 2, s);
     Readback *rb = readback_slot();
     if (!rb) return GSR_E_HIP;
-    HIP_TRY(hipMemcpyAsync(rb->pinned, geom->point_offsets + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // the scan's last wave stores D = point_offsets[N-1] straight into the pinned host word
+    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, s));
+    mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
     // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id
     // order, four 8-bit passes over the high word; ends back in depth_item) and the depth-order offsets.
@@ -226,7 +226,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
             uint64_t *t = src; src = dst; dst = t;
         }
         mark(st, 3, s);
-        HIP_TRY(gsr_launch_scan(geom->tiles_touched, ws.depth_item, ws.doff, ws.scan_tmp, N, 1, s));
+        HIP_TRY(gsr_launch_scan(geom->tiles_touched, ws.depth_item, ws.doff, ws.scan_tmp, N, 1, nullptr, s));
         mark(st, 4, s);
     }
     HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting

@@ -53,7 +53,7 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 // mode 1: values gathered through sorted depth items: v[k] = in[low32(items[k])], out = exclusive scan.
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
-                           int64_t n, int mode, hipStream_t s);
+                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s);
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096

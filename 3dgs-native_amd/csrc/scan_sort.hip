@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 
 template <int MODE>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
-                                                         int32_t *__restrict__ out, int64_t n)
+                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
         const int v = (k < n) ? (MODE == 0 ? in[k] : out[k]) : 0; // gather mode: the value was parked in out by the first kernel
         const int inc = wave_incl_scan(v);
         if (k < n) out[k] = carry + (MODE == 0 ? inc : inc - v);  // mode 0 inclusive, mode 1 exclusive
+        // the grand total goes straight to a (pinned, device-visible) host word: no separate copy kernel for D
+        if (total_out && k == n - 1) *total_out = carry + inc;
         carry += __shfl(inc, 63, 64);
     }
 }
@@ -139,21 +141,22 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     if (threadIdx.x < RADIX) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
-// one block per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum
-__global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ totals, int nb)
+// one WAVE per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ totals, int nb, int radix)
 {
-    __shared__ int lds[4];
-    int32_t *row = hist + (size_t)blockIdx.x * nb;
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= radix) return;
+    int32_t *row = hist + (size_t)d * nb;
     int carry = 0;
-    for (int base = 0; base < nb; base += 256) {
-        const int k = base + threadIdx.x;
+    for (int base = 0; base < nb; base += 64) {
+        const int k = base + lane;
         const int v = k < nb ? row[k] : 0;
-        int tot;
-        const int inc = block_incl_scan_256(v, lds, &tot);
+        const int inc = wave_incl_scan(v);
         if (k < nb) row[k] = carry + inc - v;
-        carry += tot;
+        carry += __shfl(inc, 63, 64);
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+    if (lane == 0) totals[d] = carry;
 }
 
 template <int RADIX_ITEMS, int BITS, typename ItemT>
@@ -333,17 +336,17 @@ __global__ __launch_bounds__(256) void ranges_kernel(const ItemT *__restrict__ i
 } // namespace
 
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
-                           hipStream_t s)
+                           int32_t *total_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
     const int nb = (nw + 3) / 4;
     if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n);
+        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else {
         hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n);
+        hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     }
     return hipGetLastError();
 }
@@ -355,12 +358,12 @@ static void radix_pass_bits(const ItemT *in, ItemT *out, int32_t *hist, int32_t 
     if (n <= GSR_RADIX_SMALL_N) {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, totals, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
     } else {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(256), 0, s, hist, totals, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
     }
 }
