@@ -70,10 +70,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
-    const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
     float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
-    ShRegs sh_regs;
-    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, (dbg & 4) ? 0ull : sh_rows_all(rows_valid));
     const int64_t i = min(wave_row0 + lane, N - 1); // tail lanes redo the last Gaussian and store nothing
     const bool in_range = wave_row0 + lane < N;
 
@@ -85,13 +82,19 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     bool visible = false, need_sh = false;
 
     const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
-    float p_view[4];
+    float p_view[4], p_hom[4];
     rowvec_mul44(px, py, pz, cam.view, p_view);
+    rowvec_mul44(px, py, pz, cam.proj, p_hom);
+    const float p_w = 1.0f / (p_hom[3] + 0.0000001f);
+    const float ndc_x = p_hom[0] * p_w, ndc_y = p_hom[1] * p_w;
+    // SH rows are fetched (under the covariance math) only for Gaussians that are likely to be drawn: in front of the
+    // near plane with the centre within 1.1x the image.  The rare visible Gaussian that fails this guess (a big one
+    // centred far outside) gets its row in a second, late fetch below, so the guess only affects speed.
+    const bool likely = in_range && !(p_view[2] < 0.2f) && fabsf(ndc_x) <= 1.1f && fabsf(ndc_y) <= 1.1f;
+    const unsigned long long early_mask = (dbg & 4) ? 0ull : __ballot(likely);
+    ShRegs sh_regs;
+    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, early_mask);
     if (!(p_view[2] < 0.2f)) {
-        float p_hom[4];
-        rowvec_mul44(px, py, pz, cam.proj, p_hom);
-        const float p_w = 1.0f / (p_hom[3] + 0.0000001f);
-        const float ndc_x = p_hom[0] * p_w, ndc_y = p_hom[1] * p_w;
 
         // Sigma3D = (R S)(R S)^T, R's columns = quat_rotate(q, e_c)
         const float sx = scale_mod * scales[3 * i], sy = scale_mod * scales[3 * i + 1], sz = scale_mod * scales[3 * i + 2];
@@ -162,6 +165,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
 
     sh_rows_commit(sh_regs, lds_wave, lane);
+    const unsigned long long late_mask = (dbg & 4) ? 0ull : (__ballot(need_sh) & ~early_mask);
+    if (late_mask) { // wave-uniform and rare
+        sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, late_mask);
+        sh_rows_commit_masked(sh_regs, lds_wave, lane, late_mask);
+    }
     __syncthreads(); // SH rows have landed in LDS
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian

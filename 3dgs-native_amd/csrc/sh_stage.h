@@ -36,6 +36,17 @@ __device__ __forceinline__ void sh_rows_commit(const ShRegs &regs, float4 *lds_w
     }
 }
 
+// commit only the rows named in row_mask (used for a second, partial fetch)
+__device__ __forceinline__ void sh_rows_commit_masked(const ShRegs &regs, float4 *lds_wave, int lane, unsigned long long row_mask)
+{
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int i = k * 64 + lane;
+        const int r = i / 12, c = i - r * 12;
+        if ((row_mask >> r) & 1ull) lds_wave[r * SH_ROW_F4 + c] = regs.v[k];
+    }
+}
+
 // g4: first row of the wave (global, as float4); rows_valid: rows of this wave that exist (<= 64)
 __device__ __forceinline__ void sh_rows_load(const float4 *__restrict__ g4, float4 *lds_wave, int lane, int rows_valid)
 {
