@@ -12,6 +12,6 @@ pointers.  There is no fallback implementation.
 """
 from .forward import render_gaussians  # noqa: F401
 from .backward import backward  # noqa: F401
-from . import cameras, scenes, config, dist, loss, optimizer, scheduler  # noqa: F401
+from . import cameras, scenes, config, dist, loss, optimizer, scheduler, densify, point_cloud  # noqa: F401
 
-__all__ = ["render_gaussians", "backward", "cameras", "scenes", "config", "dist", "loss", "optimizer", "scheduler"]
+__all__ = ["render_gaussians", "backward", "cameras", "scenes", "config", "dist", "loss", "optimizer", "scheduler", "densify", "point_cloud"]

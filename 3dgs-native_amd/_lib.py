@@ -52,6 +52,12 @@ class GsrAdam(C.Structure):
                 ("epsilon", C.c_float), ("iteration", C.c_int32)]
 
 
+class GsrParams(C.Structure):
+    _fields_ = [("N", C.c_int64), ("positions", vp), ("scales", vp), ("rotations", vp), ("opacities", vp), ("shs", vp)]
+
+
+MARK_CLONE, MARK_SPLIT = 0, 1
+
 EXPORTS = {
     "gsr_abi_version": (C.c_int, []),
     "gsr_strerror": (C.c_char_p, [C.c_int]),
@@ -66,6 +72,15 @@ EXPORTS = {
                                C.POINTER(GsrImage), vp, C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
     "gsr_l1_loss_grad": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
     "gsr_adam_update": (C.c_int, [C.POINTER(GsrAdam), vp]),
+    "gsr_densify_mark": (C.c_int, [C.POINTER(GsrParams), vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp]),
+    "gsr_prune_mark": (C.c_int, [C.POINTER(GsrParams), C.c_float, vp, vp]),
+    "gsr_split_removal_mask": (C.c_int, [C.c_int64, C.c_int64, vp, vp, vp]),
+    "gsr_mask_scan_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "gsr_mask_scan": (C.c_int, [C.c_int64, vp, vp, C.POINTER(C.c_int32), vp, C.c_size_t, vp]),
+    "gsr_clone_gaussians": (C.c_int, [C.POINTER(GsrParams), vp, vp, C.c_float, C.POINTER(GsrParams), vp]),
+    "gsr_split_gaussians": (C.c_int, [C.POINTER(GsrParams), vp, vp, C.c_int32, C.c_float, C.POINTER(GsrParams), vp]),
+    "gsr_compact_gaussians": (C.c_int, [C.POINTER(GsrParams), vp, vp, C.POINTER(GsrParams), vp]),
+    "gsr_reset_opacities": (C.c_int, [C.c_int64, C.c_float, vp, vp]),
     "gsr_stage_timing": (C.c_int, [C.c_int, C.c_int]),
     "gsr_stage_sampling": (C.c_int, [C.c_int]),
     "gsr_stage_times": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -51,6 +51,7 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 
 // Device-wide scan of int32.  mode 0: out[i] = inclusive scan of in[i].
 // mode 1: values gathered through sorted depth items: v[k] = in[low32(items[k])], out = exclusive scan.
+// mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
                            int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
         const int64_t k = base + r * 64 + lane;
         int v = 0;
         if (k < n) {
-            if (MODE == 0) v = in[k];
+            if (MODE != 1) v = in[k];
             else { v = in[(uint32_t)items[k]]; out[k] = v; }
         }
         s += v;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 #pragma unroll
     for (int r = 0; r < SCAN_ROUNDS; ++r) {
         const int64_t k = base + r * 64 + lane;
-        const int v = (k < n) ? (MODE == 0 ? in[k] : out[k]) : 0; // gather mode: the value was parked in out by the first kernel
+        const int v = (k < n) ? (MODE != 1 ? in[k] : out[k]) : 0; // gather mode: the value was parked in out by the first kernel
         const int inc = wave_incl_scan(v);
-        if (k < n) out[k] = carry + (MODE == 0 ? inc : inc - v);  // mode 0 inclusive, mode 1 exclusive
+        if (k < n) out[k] = carry + (MODE == 0 ? inc : inc - v);  // mode 0 inclusive, modes 1 and 2 exclusive
         // the grand total goes straight to a (pinned, device-visible) host word: no separate copy kernel for D
         if (total_out && k == n - 1) *total_out = carry + inc;
         carry += __shfl(inc, 63, 64);
@@ -344,9 +344,12 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
         hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
-    } else {
+    } else if (mode == 1) {
         hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
         hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+    } else {
+        hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
+        hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     }
     return hipGetLastError();
 }

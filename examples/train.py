@@ -3,8 +3,9 @@
 Counterpart of the reference's training iteration (train.py:920-1066) on the
 MI355X: per step each rank renders its views, forms the L1 loss and pixel gradient, runs backward, all-reduces
 the 59-float gradient arena (one RCCL collective), and applies the fused Adam update -- everything on the GPU,
-parameters resident, no per-iteration host upload.  Densification / pruning / PLY export (row f4) are not
-part of this build.
+parameters resident, no per-iteration host upload.  Then the reference's adaptive density control (row f4,
+train.py:351-713: clone / split / prune / opacity reset) runs on the replicated parameters -- it is deterministic,
+so every rank reaches the same point set without a collective -- and rank 0 writes PLY checkpoints (train.py:796-803).
 
 Targets: with --dataset <NeRF-synthetic dir> the train split (transforms_train.json + PNGs, alpha dropped as
 train.py:323-334) is used; without it, targets are renders of a hidden seeded scene from orbiting cameras.
@@ -45,6 +46,12 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--views-per-step", type=int, default=1)
     ap.add_argument("--size", type=int, default=400)
+    ap.add_argument("--densify-from", type=int, default=500)    # train.py:391-394 defaults
+    ap.add_argument("--densify-until", type=int, default=15000)
+    ap.add_argument("--densify-interval", type=int, default=100)
+    ap.add_argument("--opacity-reset-interval", type=int, default=3000)
+    ap.add_argument("--save-interval", type=int, default=500)   # config.py:32
+    ap.add_argument("--output", default=None, help="directory for point_cloud/iteration_N/point_cloud.ply")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,10 +83,14 @@ def main():
     n = args.gaussians
     P = {"positions": t(init["means"], (n, 3)), "scales": t(init["scales"], (n, 3)), "rotations": t(init["rotations"], (n, 4)),
          "opacities": t(init["opacities"], (n,)), "shs": t(init["shs"], (n * 16, 3))}
-    M, V = gsr.optimizer.make_state(P)
+    model = gsr.densify.GaussianModel(
+        P, scene_extent=gsr.densify.calculate_scene_extent([c["camera_center"] for c in cams]),
+        config={"densify_from_iter": args.densify_from, "densify_until_iter": args.densify_until, "densification_interval": args.densify_interval,
+                "opacity_reset_interval": args.opacity_reset_interval, "max_allowed_prune_ratio": 1.0, "background_color": [0.0, 0.0, 0.0]})
     sched = {k: gsr.scheduler.LRScheduler(lr) for k, lr in gsr.optimizer.DEFAULT_LR.items()}
     rng = np.random.default_rng(0)                                          # same stream on every rank -> same view batch
     for it in range(args.iterations):
+        P, M, V, n = model.params, model.adam_m, model.adam_v, model.num_points
         batch = rng.choice(len(cams), size=args.views_per_step, replace=False)
         mine = [int(batch[i]) for i in gsr.dist.views_for_rank(len(batch), rank, world)]
         arena, loss_acc = None, torch.zeros(1, device=dev)
@@ -104,7 +115,14 @@ def main():
         gsr.dist.reduce_gradients(arena, world, average=True)
         grads = gsr.dist.arena_views(arena, n)
         lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}
-        gsr.optimizer.adam_update(P, gsr.optimizer.grads_from_backward(grads), M, V, lrs, iteration=it)
+        model.grads = gsr.optimizer.grads_from_backward(grads)              # train.py:1047-1051
+        gsr.optimizer.adam_update(P, model.grads, M, V, lrs, iteration=it)
+        log = model.densification_and_pruning(it)                           # train.py:1060
+        if rank == 0 and (log["cloned"] or log["split"] or log["pruned"] or log["opacity_reset"]):
+            print(f"iter {it:5d}  densify: +{log['cloned']} cloned, {log['split']} split, -{log['pruned']} pruned"
+                  f"{', opacity reset' if log['opacity_reset'] else ''} -> {model.num_points} points")
+        if rank == 0 and args.output and (it % args.save_interval == 0 or it == args.iterations - 1):
+            gsr.point_cloud.save_ply(model.params, os.path.join(args.output, "point_cloud", f"iteration_{it}", "point_cloud.ply"), model.num_points)
         if rank == 0 and (it % 10 == 0 or it == args.iterations - 1):
             print(f"iter {it:5d}  loss {float(loss_acc.item()) / max(1, len(mine)):.6f}")
 

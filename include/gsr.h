@@ -186,6 +186,49 @@ typedef struct GsrAdam {
 } GsrAdam;
 int gsr_adam_update(const GsrAdam *adam, void *stream);
 
+/* ---- row f4: adaptive density control --------------------------------
+ * Replaces the Warp kernels the reference trainer launches in densification_and_pruning()
+ * (train.py:351-713): compute_grad_norms (train.py:398-406), mark_clone_candidates /
+ * mark_split_candidates (optimizer.py:180-239), wp.utils.array_scan(..., inclusive=False)
+ * (train.py:432,496,580,640), clone_gaussians (optimizer.py:312-365), split_gaussians
+ * (optimizer.py:242-309), mark_split_originals_for_removal + invert_mask (train.py:547-576),
+ * prune_gaussians (optimizer.py:367-385), compact_gaussians (optimizer.py:387-416) and
+ * reset_opacities (optimizer.py:141-156).  The five parameter arrays are the trainer's `params` dict. */
+typedef struct GsrParams {
+    int64_t N;
+    float *positions; /* [N*3]    */
+    float *scales;    /* [N*3]    */
+    float *rotations; /* [N*4]    */
+    float *opacities; /* [N]      */
+    float *shs;       /* [N*16*3] */
+} GsrParams;
+enum { GSR_MARK_CLONE = 0, GSR_MARK_SPLIT = 1 };
+/* mask[i] = (|pos_grad[i]| >= grad_threshold) && (max(scale_i) <= / > percent_dense*scene_extent).
+ * Rows i >= n_grad have no gradient (the reference reads past its avg_grads array there after a clone,
+ * train.py:478-494: undefined; here their norm is 0). */
+int gsr_densify_mark(const GsrParams *p, const float *pos_grad /* [n_grad*3] */, int64_t n_grad, float grad_threshold,
+                     float scene_extent, float percent_dense, int mode, int32_t *mask /* [N] out */, void *stream);
+/* valid[i] = opacities[i] > opacity_threshold */
+int gsr_prune_mark(const GsrParams *p, float opacity_threshold, int32_t *valid /* [N] out */, void *stream);
+/* valid[i] = !(i < offset && split_mask[i] == 1), i < n_total; split_mask has `offset` entries */
+int gsr_split_removal_mask(int64_t n_total, int64_t offset, const int32_t *split_mask, int32_t *valid /* [n_total] out */, void *stream);
+/* prefix = exclusive scan of mask; *count_host = prefix[N-1], the count the reference takes
+ * (`int(prefix_sum.numpy()[-1])`: the last row's own flag is NOT counted).  Synchronises the stream.
+ * scratch: gsr_mask_scan_workspace_bytes(N) device bytes. */
+size_t gsr_mask_scan_workspace_bytes(int64_t N);
+int gsr_mask_scan(int64_t N, const int32_t *mask, int32_t *prefix /* [N] out */, int32_t *count_host, void *scratch, size_t scratch_bytes,
+                  void *stream);
+/* out rows [0,N) = in rows; flagged row i is also written to row N + prefix[i] with
+ * positions + randf(3i+k)*noise_scale.  Rows that would land at or past out->N are dropped. */
+int gsr_clone_gaussians(const GsrParams *in, const int32_t *mask, const int32_t *prefix, float noise_scale, const GsrParams *out, void *stream);
+/* out rows [0,N) = in rows; flagged row i spawns n_split rows at N + prefix[i]*n_split + j with scales*scale_factor and
+ * positions + (randf(3*new_idx+k)*2-1)*0.01; rows at or past out->N are dropped (optimizer.py:288). */
+int gsr_split_gaussians(const GsrParams *in, const int32_t *mask, const int32_t *prefix, int32_t n_split, float scale_factor,
+                        const GsrParams *out, void *stream);
+/* out row prefix[i] = in row i where valid[i] != 0; rows at or past out->N are dropped */
+int gsr_compact_gaussians(const GsrParams *in, const int32_t *valid, const int32_t *prefix, const GsrParams *out, void *stream);
+int gsr_reset_opacities(int64_t N, float max_opacity, float *opacities, void *stream);
+
 /* ---- profiling aid (the only process-wide state in the library; not thread-safe) ----------------
  * With timing enabled every stage boundary of the three entry points records a hipEvent on the
  * caller's stream (about 3 us each, and kernels no longer dispatch back to back across a record: ~6 % of a
