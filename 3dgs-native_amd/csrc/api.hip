@@ -162,6 +162,8 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.rect = c.take<TileRect>((size_t)N);
     w.depth_item = c.take<uint64_t>((size_t)N);
     w.sort_tmp = c.take<uint64_t>((size_t)N);
+    w.rect_sorted = c.take<TileRect>((size_t)N);
+    w.cnt_sorted = c.take<int32_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
@@ -221,12 +223,14 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     // order, four 8-bit passes over the high word; ends back in depth_item) and the depth-order offsets.
     {
         uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < 3; ++pass) {
             HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, 8, s));
             uint64_t *t = src; src = dst; dst = t;
         }
+        // the last pass also carries each Gaussian's tile rectangle and tile count to its sorted position
+        HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.totals, N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
         mark(st, 3, s);
-        HIP_TRY(gsr_launch_scan(geom->tiles_touched, ws.depth_item, ws.doff, ws.scan_tmp, N, 1, nullptr, s));
+        HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s));
         mark(st, 4, s);
     }
     HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting
@@ -273,7 +277,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     while ((1LL << id_bits) < N) ++id_bits;
     const bool narrow = tb + id_bits <= 32;
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
-    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, s));
+    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, s));
     mark(st, 6, s);
     // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible
     //    (12 bits -> 6+6, 13 -> 7+6)

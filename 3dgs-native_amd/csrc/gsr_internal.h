@@ -38,6 +38,8 @@ struct GeomWs {
     TileRect *rect;       // [N]
     uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled; sorted by depth after gsr_forward_count
     uint64_t *sort_tmp;   // [N] ping-pong partner of depth_item
+    TileRect *rect_sorted; // [N] tile rectangles in depth order (written by the last depth-sort pass)
+    int32_t *cnt_sorted;  // [N] tile counts in depth order (same pass)
     int32_t *doff;        // [N] exclusive tile-pair offsets in depth order
     int32_t *scan_tmp;    // block sums for the scans
     int32_t *hist;        // [256 * nb(N)] radix block histograms
@@ -65,6 +67,8 @@ hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[rad
                                  int64_t n, int shift, int bits, int item_bytes, hipStream_t s);
 
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
+hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
+                                      const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s);
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
                              hipStream_t s);

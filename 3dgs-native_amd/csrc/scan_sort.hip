@@ -141,32 +141,58 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     if (threadIdx.x < RADIX) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
-// one WAVE per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum
+// one WAVE per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum.
+// The row is walked in batches of 16 coalesced rounds whose loads are all issued before the first scan: with one
+// load -> scan -> store per iteration the kernel was a chain of nb/64 memory round trips (9.8 us per launch at C3,
+// six launches per frame); batched it pays one or two.
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ totals, int nb, int radix)
 {
+    constexpr int RB = 16;
     const int lane = threadIdx.x & 63;
     const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (d >= radix) return;
     int32_t *row = hist + (size_t)d * nb;
     int carry = 0;
-    for (int base = 0; base < nb; base += 64) {
-        const int k = base + lane;
-        const int v = k < nb ? row[k] : 0;
-        const int inc = wave_incl_scan(v);
-        if (k < nb) row[k] = carry + inc - v;
-        carry += __shfl(inc, 63, 64);
+    for (int base = 0; base < nb; base += 64 * RB) {
+        int v[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int k = base + r * 64 + lane;
+            v[r] = k < nb ? row[k] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int inc = wave_incl_scan(v[r]);
+            v[r] = carry + inc - v[r];
+            carry += __shfl(inc, 63, 64);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int k = base + r * 64 + lane;
+            if (k < nb) row[k] = v[r];
+        }
     }
     if (lane == 0) totals[d] = carry;
 }
 
-template <int RADIX_ITEMS, int BITS, typename ItemT>
+// CARRY (last depth pass only): the item's tile rectangle is fetched by id and written, with its tile count, to the
+// item's final position -- so the depth-order scan and the expansion stream rect_sorted / cnt_sorted instead of each
+// gathering through the sorted ids (two random 64-byte-sector reads per Gaussian become one).
+struct ScatterCarry {
+    const TileRect *rect;   // [n] by id
+    TileRect *rect_sorted;  // [n] in output order
+    int32_t *cnt_sorted;    // [n] (x1-x0)*(y1-y0) in output order
+};
+
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
-                                                            int64_t n, int shift, int nb)
+                                                            int64_t n, int shift, int nb, ScatterCarry carry)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
     __shared__ ItemT s_items[CHUNK];    // items reordered by digit
+    __shared__ TileRect s_rect[CARRY ? CHUNK : 1]; // CARRY: the items' rectangles, reordered with them
     __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
     __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
     __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
@@ -185,12 +211,15 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
 
     // pass 1: rank every item among equal digits of its wave, in index order
     ItemT item[RADIX_ITEMS];
+    TileRect rc[CARRY ? RADIX_ITEMS : 1];
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
         const bool valid = k < n;
         item[r] = valid ? in[k] : (ItemT)~(ItemT)0;
+        if constexpr (CARRY) // issued here so the random fetch is in flight during the ranking
+            rc[r] = valid ? carry.rect[(uint32_t)item[r]] : TileRect{0, 0, 0, 0};
         const int d = (int)((item[r] >> shift) & (RADIX - 1));
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -243,7 +272,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const int64_t k = wave_base + r * 64 + lane;
         if (k < n) {
             const int d = (int)((item[r] >> shift) & (RADIX - 1));
-            s_items[s_dstart[d] + s_wcnt[w][d] + rank[r]] = item[r];
+            const int slot = s_dstart[d] + s_wcnt[w][d] + rank[r];
+            s_items[slot] = item[r];
+            if constexpr (CARRY) s_rect[slot] = rc[r];
         }
     }
     __syncthreads();
@@ -256,7 +287,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         if (slot < valid_n) {
             const ItemT it = s_items[slot];
             const int d = (int)((it >> shift) & (RADIX - 1));
-            out[(int64_t)s_gbase[d] + (slot - s_dstart[d])] = it;
+            const int64_t pos = (int64_t)s_gbase[d] + (slot - s_dstart[d]);
+            out[pos] = it;
+            if constexpr (CARRY) {
+                const TileRect q = s_rect[slot];
+                carry.rect_sorted[pos] = q;
+                carry.cnt_sorted[pos] = ((int)q.x1 - (int)q.x0) * ((int)q.y1 - (int)q.y0);
+            }
         }
     }
 }
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
         const uint64_t it = sorted[k];
         id = (uint32_t)it;
         off = doff[k];
-        if ((uint32_t)(it >> 32) != 0xFFFFFFFFu) rc = rect[id]; // culled Gaussians (sorted last) own no items
+        rc = rect[k]; // rectangles arrive in depth order (carried by the last sort pass); culled Gaussians have empty ones
     }
     s_off[w][lane] = off;
     s_rect[w][lane] = rc;
@@ -362,12 +399,12 @@ static void radix_pass_bits(const ItemT *in, ItemT *out, int32_t *hist, int32_t 
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{});
     } else {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{});
     }
 }
 
@@ -394,6 +431,26 @@ hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32
     if (n <= 0) return hipSuccess;
     if (item_bytes == 4) return radix_pass_any<uint32_t>((const uint32_t *)in, (uint32_t *)out, hist, totals, n, shift, bits, s);
     return radix_pass_any<uint64_t>((const uint64_t *)in, (uint64_t *)out, hist, totals, n, shift, bits, s);
+}
+
+// The last pass of the depth sort (8-bit digit of 64-bit items) with the rectangle carry.
+hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
+                                      const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const ScatterCarry carry{rect, rect_sorted, cnt_sorted};
+    if (n <= GSR_RADIX_SMALL_N) {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry);
+    } else {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry);
+    }
+    return hipGetLastError();
 }
 
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,

@@ -45,6 +45,10 @@ def reduce_gradients(arena, world_size=None, average=True):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return arena
     ws = dist.get_world_size() if world_size is None else world_size
+    if average and arena.is_cuda and dist.get_backend() == "nccl":
+        # RCCL scales inside the collective (ncclAvg): no second 236 B/Gaussian pass over the arena
+        dist.all_reduce(arena, op=dist.ReduceOp.AVG)
+        return arena
     dist.all_reduce(arena, op=dist.ReduceOp.SUM)
     if average:
         arena.mul_(1.0 / ws)   # mean keeps densify_grad_threshold semantics (reference config.py:54)
