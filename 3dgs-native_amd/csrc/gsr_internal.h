@@ -52,7 +52,6 @@ GeomWs gsr_carve_geom(void *base, int64_t N);
 hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s);
 
 // Device-wide scan of int32.  mode 0: out[i] = inclusive scan of in[i].
-// mode 1: values gathered through sorted depth items: v[k] = in[low32(items[k])], out = exclusive scan.
 // mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,

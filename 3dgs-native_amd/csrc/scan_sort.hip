@@ -59,16 +59,13 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *lds4 /* >= 4 ints
 // ---------------------------------------------------------------------------------------------
 // device-wide scan in two kernels: per-wave sums -> per-wave rescan (each wave first adds up the sums before it).
 // The unit of work is a WAVE owning 1024 consecutive items, walked in 16 rounds of 64 so every load and
-// store is a fully coalesced 256-byte access and no block barrier is needed.  In gather mode (values
-// fetched through the depth-sorted ids, 4-byte random reads) the first kernel parks the gathered value
-// in `out`, so the random gather happens once and the second kernel streams.
+// store is a fully coalesced 256-byte access and no block barrier is needed.
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_WAVE_ITEMS = 1024;
 constexpr int SCAN_ROUNDS = SCAN_WAVE_ITEMS / 64;
 
 template <int MODE>
-__global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restrict__ in, const uint64_t *__restrict__ items,
-                                                          int32_t *__restrict__ out, int32_t *__restrict__ wave_sums, int64_t n)
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ wave_sums, int64_t n)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -78,12 +75,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 #pragma unroll
     for (int r = 0; r < SCAN_ROUNDS; ++r) {
         const int64_t k = base + r * 64 + lane;
-        int v = 0;
-        if (k < n) {
-            if (MODE != 1) v = in[k];
-            else { v = in[(uint32_t)items[k]]; out[k] = v; }
-        }
-        s += v;
+        s += (k < n) ? in[k] : 0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
@@ -98,21 +90,35 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t base = wid * SCAN_WAVE_ITEMS;
     if (base >= n) return;
+    // all 16 rounds are loaded before anything else: left to itself the compiler emits load -> wait -> scan -> store per
+    // round (the stores' branches fence the loads), a chain of 16 memory round trips per wave
+    int v[SCAN_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        const int64_t k = base + r * 64 + lane;
+        v[r] = (k < n) ? in[k] : 0;
+    }
     // this wave's offset = sum of the sums of all earlier waves: a few KB read per wave beats a third kernel launch
     int carry = 0;
     for (int64_t j = lane; j < wid; j += 64) carry += wave_sums[j];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) carry += __shfl_xor(carry, d, 64);
+    int32_t total = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        const int inc = wave_incl_scan(v[r]);
+        const int64_t k = base + r * 64 + lane;
+        if (k == n - 1) total = carry + inc;
+        v[r] = carry + (MODE == 0 ? inc : inc - v[r]); // mode 0 inclusive, mode 2 exclusive
+        carry += __shfl(inc, 63, 64);
+    }
 #pragma unroll
     for (int r = 0; r < SCAN_ROUNDS; ++r) {
         const int64_t k = base + r * 64 + lane;
-        const int v = (k < n) ? (MODE != 1 ? in[k] : out[k]) : 0; // gather mode: the value was parked in out by the first kernel
-        const int inc = wave_incl_scan(v);
-        if (k < n) out[k] = carry + (MODE == 0 ? inc : inc - v);  // mode 0 inclusive, modes 1 and 2 exclusive
-        // the grand total goes straight to a (pinned, device-visible) host word: no separate copy kernel for D
-        if (total_out && k == n - 1) *total_out = carry + inc;
-        carry += __shfl(inc, 63, 64);
+        if (k < n) out[k] = v[r];
     }
+    // the grand total goes straight to a (pinned, device-visible) host word: no separate copy kernel for D
+    if (total_out && base + SCAN_WAVE_ITEMS >= n && ((n - 1 - base) & 63) == lane) *total_out = total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -132,10 +138,17 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     if (threadIdx.x < RADIX) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * CHUNK;
-#pragma unroll 4
+    // loads first, LDS atomics after: otherwise every round waits for its own load (RADIX_ITEMS serial round trips)
+    ItemT item[RADIX_ITEMS];
+#pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = base + r * 256 + threadIdx.x;
-        if (k < n) atomicAdd(&h[(int)((in[k] >> shift) & (RADIX - 1))], 1);
+        item[r] = k < n ? in[k] : (ItemT)0;
+    }
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+        const int64_t k = base + r * 256 + threadIdx.x;
+        if (k < n) atomicAdd(&h[(int)((item[r] >> shift) & (RADIX - 1))], 1);
     }
     __syncthreads();
     if (threadIdx.x < RADIX) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
     __shared__ ItemT s_items[CHUNK];    // items reordered by digit
-    __shared__ TileRect s_rect[CARRY ? CHUNK : 1]; // CARRY: the items' rectangles, reordered with them
+    __shared__ unsigned long long s_rect[CARRY ? CHUNK : 1]; // CARRY: the items' rectangles (raw bits), reordered with them
     __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
     __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
     __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
@@ -211,15 +224,30 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
 
     // pass 1: rank every item among equal digits of its wave, in index order
     ItemT item[RADIX_ITEMS];
-    TileRect rc[CARRY ? RADIX_ITEMS : 1];
+    unsigned long long rc[CARRY ? RADIX_ITEMS : 1]; // raw TileRect bits
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
+    // every load is issued before the ranking starts (the ranking's branches would otherwise pin each load to its own
+    // round: RADIX_ITEMS serial memory round trips per wave)
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+        const int64_t k = wave_base + r * 64 + lane;
+        const ItemT v = in[k < n ? k : n - 1];
+        item[r] = k < n ? v : (ItemT)~(ItemT)0;
+    }
+    if constexpr (CARRY) { // the random rectangle fetches are in flight during the ranking
+        // raw 8-byte loads at a clamped index, no branch: as `valid ? rect[id] : {}` each fetch got its own exec-masked
+        // block with a full wait behind it, i.e. RADIX_ITEMS serial random round trips
+#pragma unroll
+        for (int r = 0; r < RADIX_ITEMS; ++r) {
+            const int64_t k = wave_base + r * 64 + lane;
+            const uint32_t id = k < n ? (uint32_t)item[r] : 0u;
+            rc[r] = reinterpret_cast<const unsigned long long *>(carry.rect)[id];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
         const bool valid = k < n;
-        item[r] = valid ? in[k] : (ItemT)~(ItemT)0;
-        if constexpr (CARRY) // issued here so the random fetch is in flight during the ranking
-            rc[r] = valid ? carry.rect[(uint32_t)item[r]] : TileRect{0, 0, 0, 0};
         const int d = (int)((item[r] >> shift) & (RADIX - 1));
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -290,9 +318,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
             const int64_t pos = (int64_t)s_gbase[d] + (slot - s_dstart[d]);
             out[pos] = it;
             if constexpr (CARRY) {
-                const TileRect q = s_rect[slot];
-                carry.rect_sorted[pos] = q;
-                carry.cnt_sorted[pos] = ((int)q.x1 - (int)q.x0) * ((int)q.y1 - (int)q.y0);
+                const unsigned long long q = s_rect[slot]; // TileRect {x0, y0, x1, y1}, 16 bits each, little endian
+                reinterpret_cast<unsigned long long *>(carry.rect_sorted)[pos] = q;
+                const int x0 = (int)(q & 0xFFFF), y0 = (int)((q >> 16) & 0xFFFF), x1 = (int)((q >> 32) & 0xFFFF), y1 = (int)(q >> 48);
+                carry.cnt_sorted[pos] = (x1 - x0) * (y1 - y0);
             }
         }
     }
@@ -378,15 +407,15 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     if (n <= 0) return hipSuccess;
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
     const int nb = (nw + 3) / 4;
+    (void)items;
     if (mode == 0) {
-        hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
+        hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
         hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
-    } else if (mode == 1) {
-        hipLaunchKernelGGL(scan_reduce_kernel<1>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<1>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
-    } else {
-        hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, items, out, block_tmp, n);
+    } else if (mode == 2) {
+        hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
         hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+    } else {
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
