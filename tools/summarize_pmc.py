@@ -12,8 +12,9 @@ import sys
 from collections import defaultdict
 
 STAGE_OF = [("preprocess_kernel", "preprocess"), ("blend_forward_kernel", "blend_fwd"), ("blend_backward_splat_kernel", "blend_bwd"),
-            ("geom_backward_kernel", "geom_bwd"), ("expand_kernel", "expand"), ("ranges_kernel", "ranges"), ("scan_", "scan"),
-            ("pack_records_kernel", "bwd_prep")]
+            ("geom_backward_kernel", "geom_bwd"), ("expand_kernel", "expand"), ("ranges_kernel", "ranges"), ("scan_reduce_kernel<0>", "scan"),
+            ("scan_final_kernel<0>", "scan"), ("scan_reduce_kernel<2>", "depth_scan"), ("scan_final_kernel<2>", "depth_scan"),
+            ("pack_records_kernel", "bwd_prep"), ("fillBufferAligned", "bwd_prep")]
 
 
 def short(name):
