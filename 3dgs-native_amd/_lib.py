@@ -39,7 +39,7 @@ class GsrImage(C.Structure):
 
 class GsrGrads(C.Structure):
     _fields_ = [("dL_dmean3D", vp), ("dL_dscale", vp), ("dL_drot", vp), ("dL_dopacity", vp), ("dL_dshs", vp),
-                ("dL_dcolor", vp), ("dL_dmean2D", vp), ("dL_dconic", vp)]
+                ("dL_dcolor", vp), ("dL_dmean2D", vp), ("dL_dconic", vp), ("dL_drgb", vp)]
 
 
 class GsrAdamGroup(C.Structure):
@@ -72,6 +72,7 @@ EXPORTS = {
                                C.POINTER(GsrImage), vp, C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
     "gsr_l1_loss_grad": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
     "gsr_adam_update": (C.c_int, [C.POINTER(GsrAdam), vp]),
+    "gsr_sh_grad_from_views": (C.c_int, [C.c_int64, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_float, vp, vp]),
     "gsr_densify_mark": (C.c_int, [C.POINTER(GsrParams), vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp]),
     "gsr_prune_mark": (C.c_int, [C.POINTER(GsrParams), C.c_float, vp, vp]),
     "gsr_split_removal_mask": (C.c_int, [C.c_int64, C.c_int64, vp, vp, vp]),
@@ -103,7 +104,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gsr_abi_version() != 1:
+        if h.gsr_abi_version() != 2:
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib

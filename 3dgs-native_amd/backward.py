@@ -5,6 +5,12 @@ the reference, whose real dL/dSigma3D is a local that never leaves backward_prep
 The five optimizer gradients are views into one flat float32 arena (`_arena`, 59 floats per
 Gaussian: mean3D | scale | rot | opacity | shs) so data-parallel training reduces them with a single
 RCCL all-reduce.
+
+One keyword beyond the reference's: `sh_gradient="factored"` (view-parallel training, dist.py) leaves the 48-float SH
+gradient unwritten and returns instead the 3-float colour gradient it is an outer product of, as a self-contained view
+payload (`_view_payload`: N rows, then the camera position); `_arena` is then the 11 floats mean3D | scale | rot | opacity
+and `dL_dshs` is None until `dist.sh_gradients_from_views` rebuilds it from all views' payloads ("both" returns the dense
+arena and the payload of the same call).
 """
 import ctypes as C
 
@@ -37,7 +43,10 @@ def _get(buf, key):
 def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=None, rotations=None, scale_modifier=1.0,
              viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5, image_height=256, image_width=256, campos=None,
              radii=None, means2D=None, conic_opacity=None, rgb=None, clamped=None, cov3Ds=None, geom_buffer=None,
-             binning_buffer=None, img_buffer=None, degree=3, debug=False):
+             binning_buffer=None, img_buffer=None, degree=3, debug=False, *, sh_gradient="dense"):
+    if sh_gradient not in ("dense", "factored", "both"):
+        raise ValueError("sh_gradient must be 'dense', 'factored' or 'both'")
+    factored = sh_gradient == "factored"
     L = _lib.lib()
     dev = _host.device_of(means3D, dL_dpixels, shs, radii)
     H, W = int(image_height), int(image_width)
@@ -80,18 +89,26 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges))
     img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
 
-    arena = torch.empty(N * 59, dtype=f32, device=dev)
     o = [0, 3 * N, 6 * N, 10 * N, 11 * N, 59 * N]
+    payload = None
+    if factored:
+        arena = torch.empty(N * 11, dtype=f32, device=dev)
+        payload = torch.empty(N * 3 + 4, dtype=f32, device=dev)   # its own allocation: aligned for the collective
+        dL_dsh = None
+    else:
+        arena = torch.empty(N * 59, dtype=f32, device=dev)
+        dL_dsh = arena[o[4]:o[5]].view(N * 16, 3)   # always N*16 rows: the reference under-allocates for degree < 3 (quirk Q6)
+        if sh_gradient == "both":                   # dense gradient AND the payload it factors into (tests, debugging)
+            payload = torch.empty(N * 3 + 4, dtype=f32, device=dev)
     dL_dmean3D = arena[o[0]:o[1]].view(N, 3)
     dL_dscale = arena[o[1]:o[2]].view(N, 3)
     dL_drot = arena[o[2]:o[3]].view(N, 4)
     dL_dopacity = arena[o[3]:o[4]]
-    dL_dsh = arena[o[4]:o[5]].view(N * 16, 3)   # always N*16 rows: the reference under-allocates for degree < 3 (quirk Q6)
     dL_dcolor = torch.empty((N, 3), dtype=f32, device=dev)
     dL_dmean2D = torch.empty((N, 3), dtype=f32, device=dev)
     dL_dconic = torch.empty((N, 4), dtype=f32, device=dev)
     grads = _lib.GsrGrads(_host.ptr(dL_dmean3D), _host.ptr(dL_dscale), _host.ptr(dL_drot), _host.ptr(dL_dopacity),
-                          _host.ptr(dL_dsh), _host.ptr(dL_dcolor), _host.ptr(dL_dmean2D), _host.ptr(dL_dconic))
+                          _host.ptr(dL_dsh), _host.ptr(dL_dcolor), _host.ptr(dL_dmean2D), _host.ptr(dL_dconic), _host.ptr(payload))
     with torch.cuda.device(dev):
         ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
         _lib.check(L.gsr_backward(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
@@ -101,4 +118,5 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
         "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,
         "dL_dcov3D": _zeros_cov3d(N, dev),
         "_arena": arena,
+        "_view_payload": payload,
     }

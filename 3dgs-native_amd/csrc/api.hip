@@ -306,7 +306,7 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     if (int rc = check_scene_cam(scene, camera)) return rc;
     const int64_t N = scene->N;
     if (N == 0) return GSR_OK;
-    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || !grads->dL_dshs ||
+    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || (!grads->dL_dshs && !grads->dL_drgb) ||
         !grads->dL_dcolor || !grads->dL_dmean2D || !grads->dL_dconic)
         return GSR_E_NULL;
     if (!geom || !geom->radii || !geom->xy || !geom->cov3D || !geom->rgb || !geom->conic_opacity || !geom->clamped_state) return GSR_E_NULL;

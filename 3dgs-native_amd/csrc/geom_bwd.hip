@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     const float *__restrict__ shs, int degree, CamK cam, float h_x, float h_y, const int32_t *__restrict__ radii,
     const float *__restrict__ cov3Ds, const float *__restrict__ clamped_state, const GradRec *__restrict__ acc,
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dscale, float *__restrict__ dL_drot, float *__restrict__ dL_dopacity,
-    float *__restrict__ dL_dshs, float *__restrict__ dL_dcolor, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic)
+    float *__restrict__ dL_dshs, float *__restrict__ dL_dcolor, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic,
+    float *__restrict__ dL_drgb)
 {
     // SH rows (input coefficients, then in place the output gradients) live in LDS; moved cooperatively
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     float o_mean[3] = {0.f, 0.f, 0.f}, o_scale[3] = {0.f, 0.f, 0.f}, o_rot[4] = {0.f, 0.f, 0.f, 0.f};
     float mean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int sh_written = 0; // number of leading SH coefficients whose gradient was written into the LDS row
+    float o_rgb[3] = {0.f, 0.f, 0.f}; // dL_dcolor * (1 - clamped) where the SH backward runs, else 0 (optional output)
     bool vis = false;
     if (in_range) {
 
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                 float dRGB[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) dRGB[c] = g_col[c] * (1.0f + (-1.0f * clamped_state[3 * idx + c]));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o_rgb[c] = dRGB[c];
                 const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
                 float dx_[3] = {0.f, 0.f, 0.f}, dy_[3] = {0.f, 0.f, 0.f}, dz_[3] = {0.f, 0.f, 0.f};
                 // in-place: every read of coefficient k (SHV) happens before its slot is overwritten (OUT)
@@ -312,9 +316,84 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) { dL_dmean3D[3 * idx + k] = o_mean[k]; dL_dscale[3 * idx + k] = o_scale[k]; }
     *reinterpret_cast<float4 *>(dL_drot + 4 * idx) = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+    if (dL_drgb) {
+        dL_drgb[3 * idx] = o_rgb[0]; dL_drgb[3 * idx + 1] = o_rgb[1]; dL_drgb[3 * idx + 2] = o_rgb[2];
+        if (idx == 0) { // the payload's trailer: where this view was taken from
+            dL_drgb[3 * N] = cam.campos[0]; dL_drgb[3 * N + 1] = cam.campos[1]; dL_drgb[3 * N + 2] = cam.campos[2]; dL_drgb[3 * N + 3] = 0.0f;
+        }
+    }
     // coefficients that got no gradient (culled Gaussian, lower degree) are zero, as in the reference's zero-initialised array
     for (int k = sh_written * 3; k < 48; ++k) row[k] = 0.0f;
     } // in_range
+    __syncthreads();
+    if (dL_dshs && rows_valid > 0) sh_rows_store(reinterpret_cast<float4 *>(dL_dshs) + wave_row0 * 12, lds_wave, lane, rows_valid);
+}
+
+// ---- SH gradient rebuilt from V views' colour gradients (gsr_sh_grad_from_views) ----
+// One lane per Gaussian: per view it normalises the direction once, forms the 16 basis values with the expressions (and
+// rounding) of the single-view kernel above, and adds basis_k * drgb_c into 48 accumulators; the finished row goes out
+// through the same LDS image as the SH rows everywhere else (12 coalesced 1-KiB stores per wave).
+struct ViewSet {
+    const float *payload[GSR_MAX_VIEWS]; // [N*3] colour-gradient rows, then campos[3]
+};
+
+__global__ __launch_bounds__(256) void sh_grad_from_views_kernel(int64_t N, const float *__restrict__ means, int degree, int V, ViewSet vs,
+                                                                 float scale, float *__restrict__ dL_dshs)
+{
+    __shared__ float4 s_rows[4 * SH_WAVE_F4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
+    const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
+    float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
+    const int64_t i = wave_row0 + lane;
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc[k] = 0.0f;
+    if (i < N) {
+        const float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        for (int v = 0; v < V; ++v) {
+            const float *cp = vs.payload[v] + 3 * N; // wave-uniform: scalar loads
+            const float d[3] = {m[0] - cp[0], m[1] - cp[1], m[2] - cp[2]};
+            const float len = sqrtf(dot3(d, d));
+            const float *gp = vs.payload[v] + 3 * i;
+            const float g[3] = {gp[0], gp[1], gp[2]};
+            if (len < 1e-8f) continue; // backward.py:84-86: no SH gradient for a Gaussian at the camera centre
+            const float x = d[0] / len, y = d[1] / len, z = d[2] / len;
+            float bk[16];
+            const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+            bk[0] = SH_C0;
+            int nb = 1;
+            if (degree > 0) {
+                bk[1] = -SH_C1 * y; bk[2] = SH_C1 * z; bk[3] = -SH_C1 * x;
+                nb = 4;
+                if (degree > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                                C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+                    bk[4] = C2_0 * xy; bk[5] = C2_1 * yz; bk[6] = C2_2 * (2.0f * zz - xx - yy); bk[7] = C2_3 * xz; bk[8] = C2_4 * (xx - yy);
+                    nb = 9;
+                    if (degree > 2) {
+                        const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                                    C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                                    C3_6 = -0.5900435899266435f;
+                        bk[9] = C3_0 * y * (3.0f * xx - yy); bk[10] = C3_1 * xy * z; bk[11] = C3_2 * y * (4.0f * zz - xx - yy);
+                        bk[12] = C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); bk[13] = C3_4 * x * (4.0f * zz - xx - yy);
+                        bk[14] = C3_5 * z * (xx - yy); bk[15] = C3_6 * x * (xx - 3.0f * yy);
+                        nb = 16;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < nb) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[3 * k + c] += bk[k] * g[c];
+                }
+        }
+    }
+    float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
+#pragma unroll
+    for (int k = 0; k < 48; ++k) row[k] = acc[k] * scale;
     __syncthreads();
     if (rows_valid > 0) sh_rows_store(reinterpret_cast<float4 *>(dL_dshs) + wave_row0 * 12, lds_wave, lane, rows_valid);
 }
@@ -329,6 +408,22 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
     const float h_x = cam.focal_x, h_y = cam.focal_y;
     hipLaunchKernelGGL(geom_backward_kernel, dim3((unsigned)gsr_div_up(sc.N, 256)), dim3(256), 0, s, sc.N, sc.means, sc.scales,
                        sc.rotations, sc.sh, sc.sh_degree, cam, h_x, h_y, g.radii, g.cov3D, g.clamped_state, acc, gr.dL_dmean3D,
-                       gr.dL_dscale, gr.dL_drot, gr.dL_dopacity, gr.dL_dshs, gr.dL_dcolor, gr.dL_dmean2D, gr.dL_dconic);
+                       gr.dL_dscale, gr.dL_drot, gr.dL_dopacity, gr.dL_dshs, gr.dL_dcolor, gr.dL_dmean2D, gr.dL_dconic, gr.dL_drgb);
     return hipGetLastError();
+}
+
+extern "C" int gsr_sh_grad_from_views(int64_t N, const float *means, int32_t sh_degree, int32_t V, const float *const *payloads, float scale,
+                                      float *dL_dshs, void *stream)
+{
+    if (N < 0 || V < 1 || V > GSR_MAX_VIEWS || sh_degree < 0 || sh_degree > 3 || N > ((int64_t)1 << 27)) return GSR_E_DIMS;
+    if (N == 0) return GSR_OK;
+    if (!means || !payloads || !dL_dshs) return GSR_E_NULL;
+    ViewSet vs;
+    for (int v = 0; v < GSR_MAX_VIEWS; ++v) {
+        vs.payload[v] = v < V ? payloads[v] : nullptr;
+        if (v < V && !payloads[v]) return GSR_E_NULL;
+    }
+    hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3((unsigned)gsr_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means,
+                       (int)sh_degree, (int)V, vs, scale, dL_dshs);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
 }

@@ -7,8 +7,10 @@ synthetic 800x800, 1M Gaussians, SH degree 3 (config "C3", SURVEY.md section 8(d
 
 A step = one render_gaussians() + one backward() of one camera view per GPU, all inputs already
 resident in HBM (device torch tensors), dL/dpixels fixed.  With N GPUs every rank holds the full
-(replicated) scene and renders its own view; the 59-float-per-Gaussian gradient arena is summed with
-ONE RCCL all-reduce per step and scaled by 1/N.  `value` = N * W * H / step time.
+(replicated) scene and renders its own view, and the step ends with every rank holding the gradient averaged over the N
+views: 11 of the 59 floats per Gaussian are all-reduced, the 48-float SH gradient -- an outer
+product of the view's SH basis and a 3-float colour gradient -- is exchanged as those 3 floats (all-gather) and rebuilt
+locally (3dgs-native_amd/dist.py; `--dense-exchange` all-reduces all 59 instead).  `value` = N * W * H / step time.
 
 The JSON line also carries
   roofline     -- the dominant kernel (longest average stage) measured with HIP events recorded by the
@@ -64,6 +66,8 @@ def main():
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend; nccl is RCCL (default). gloo + "
                     "--single-device rehearse the N>1 path on a one-GPU box")
+    ap.add_argument("--dense-exchange", action="store_true", help="N>1: all-reduce the full 59-float arena instead of the factored "
+                    "exchange (11 floats all-reduced + 3 all-gathered per Gaussian, SH gradient rebuilt locally)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
@@ -101,6 +105,8 @@ def main():
                tan_fovy=cam["tan_fovy"], image_height=H, image_width=W, sh=shs, degree=3, campos=cam["camera_center"],
                prefiltered=False, antialiasing=False, clamped=True)
 
+    sh_out = torch.empty((N * 16, 3), dtype=torch.float32, device=dev) if world > 1 else None
+
     def step():
         img, depth, buf = gsr.render_gaussians(**fkw)
         grads = gsr.backward(
@@ -109,8 +115,13 @@ def main():
             tan_fovy=fkw["tan_fovy"], image_height=H, image_width=W, campos=fkw["campos"], radii=buf["radii"],
             means2D=buf["points_xy_image"], conic_opacity=buf["conic_opacity"], rgb=buf["colors"], cov3Ds=buf["cov3Ds"],
             clamped=buf["clamped_state"], geom_buffer=None, binning_buffer={"point_list": buf["point_list"]},
-            img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]}, degree=3)
-        if world > 1:
+            img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]}, degree=3,
+            sh_gradient="factored" if (world > 1 and not args.dense_exchange) else "dense")
+        if world > 1 and not args.dense_exchange:
+            # factored exchange: all-reduce 11 floats per Gaussian, all-gather 3, rebuild the averaged SH gradient locally
+            gathered = gsr.dist.exchange_factored(grads["_arena"], grads["_view_payload"])
+            grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(means, gathered, 3, average=True, out=sh_out)
+        elif world > 1:
             gsr.dist.reduce_gradients(grads["_arena"], world)
         return buf, grads
 
@@ -155,7 +166,8 @@ def main():
         "config": {"workload": f"{args.config}: synthetic {W}x{H}, {N} Gaussians, SH degree 3, seed {cfg['seed']}, forward+backward, "
                                f"Lego train pose 0" + (" rotated per rank" if world > 1 else ""),
                    "width": W, "height": H, "gaussians": N, "visible": Nv, "tile_pairs_D": D, "views_per_step": world,
-                   "parallelism": f"dp{world}: one view per GPU, replicated Gaussians" + (", RCCL all-reduce of the 59-float gradient arena" if world > 1 else "")},
+                   "parallelism": f"dp{world}: one view per GPU, replicated Gaussians" + ((", RCCL all-reduce of the 59-float gradient arena" if args.dense_exchange else
+                                                                                        ", RCCL all-reduce of 11 floats + all-gather of 3 floats per Gaussian, SH gradient rebuilt per rank") if world > 1 else "")},
     }
 
     if rank == 0:

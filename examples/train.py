@@ -2,7 +2,7 @@
 """
 Counterpart of the reference's training iteration (train.py:920-1066) on the
 MI355X: per step each rank renders its views, forms the L1 loss and pixel gradient, runs backward, all-reduces
-the 59-float gradient arena (one RCCL collective), and applies the fused Adam update -- everything on the GPU,
+the gradient (11 floats all-reduced + 3 floats all-gathered per Gaussian, the SH gradient rebuilt per rank: dist.py), and applies the fused Adam update -- everything on the GPU,
 parameters resident, no per-iteration host upload.  Then the reference's adaptive density control (row f4,
 train.py:351-713: clone / split / prune / opacity reset) runs on the replicated parameters -- it is deterministic,
 so every rank reaches the same point set without a collective -- and rank 0 writes PLY checkpoints (train.py:796-803).
@@ -51,16 +51,19 @@ def main():
     ap.add_argument("--densify-interval", type=int, default=100)
     ap.add_argument("--opacity-reset-interval", type=int, default=3000)
     ap.add_argument("--save-interval", type=int, default=500)   # config.py:32
+    ap.add_argument("--backend", default=None, help="collective backend (default: nccl = RCCL); gloo + --single-device rehearses N ranks on one GPU")
+    ap.add_argument("--single-device", action="store_true")
     ap.add_argument("--output", default=None, help="directory for point_cloud/iteration_N/point_cloud.ply")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.single_device else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rank = 0
     if world > 1:
-        rank, world = gsr.dist.init_from_env(device=dev)
+        rank, world = gsr.dist.init_from_env(backend=args.backend, device=dev)
 
     bg = np.zeros(3, np.float32)
     if args.dataset:
@@ -93,7 +96,8 @@ def main():
         P, M, V, n = model.params, model.adam_m, model.adam_v, model.num_points
         batch = rng.choice(len(cams), size=args.views_per_step, replace=False)
         mine = [int(batch[i]) for i in gsr.dist.views_for_rank(len(batch), rank, world)]
-        arena, loss_acc = None, torch.zeros(1, device=dev)
+        arena, loss_acc, payloads = None, torch.zeros(1, device=dev), []
+        factored = world > 1      # N > 1: exchange 11 + 3 floats per Gaussian instead of 59 (dist.py)
         for v in mine:
             c = cams[v]
             kw = dict(background=bg, means3D=P["positions"], opacity=P["opacities"], scales=P["scales"], rotations=P["rotations"],
@@ -107,13 +111,27 @@ def main():
                              tan_fovy=kw["tan_fovy"], image_height=c["height"], image_width=c["width"], campos=kw["campos"],
                              radii=buf["radii"], means2D=buf["points_xy_image"], conic_opacity=buf["conic_opacity"], rgb=buf["colors"],
                              cov3Ds=buf["cov3Ds"], clamped=buf["clamped_state"], binning_buffer={"point_list": buf["point_list"]},
-                             img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]})
+                             img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]},
+                             sh_gradient="factored" if factored else "dense")
             arena = g["_arena"] if arena is None else arena.add_(g["_arena"])
-        if arena is None:
-            arena = torch.zeros(gsr.dist.ARENA_FLOATS * n, device=dev)
-        arena.mul_(1.0 / max(1, len(batch)) * world)                        # mean over the batch after the /world below
-        gsr.dist.reduce_gradients(arena, world, average=True)
-        grads = gsr.dist.arena_views(arena, n)
+            if factored:
+                payloads.append(g["_view_payload"])
+        per_rank = -(-len(batch) // world)                                  # views per rank, rounded up
+        if factored:
+            if arena is None:
+                arena = torch.zeros(gsr.dist.SMALL_ARENA_FLOATS * n, device=dev)
+            while len(payloads) < per_rank:                                 # ranks with a view less gather a zero payload
+                payloads.append(torch.zeros(3 * n + 4, device=dev))
+            arena.mul_(world / len(batch))                                  # mean over the batch after the /world of the average
+            gathered = gsr.dist.exchange_factored(arena, torch.stack(payloads).view(-1), average=True)
+            grads = gsr.dist.small_arena_views(arena, n)
+            grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(P["positions"], gathered.view(world * per_rank, 3 * n + 4), 3,
+                                                                scale=1.0 / len(batch))
+        else:
+            if arena is None:
+                arena = torch.zeros(gsr.dist.ARENA_FLOATS * n, device=dev)
+            arena.mul_(1.0 / max(1, len(batch)))
+            grads = gsr.dist.arena_views(arena, n)
         lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}
         model.grads = gsr.optimizer.grads_from_backward(grads)              # train.py:1047-1051
         gsr.optimizer.adam_update(P, model.grads, M, V, lrs, iteration=it)

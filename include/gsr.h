@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 #define GSR_TILE 16
 #define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
 #define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
@@ -122,6 +122,11 @@ typedef struct GsrGrads {
     float *dL_dcolor;   /* [N*3] */
     float *dL_dmean2D;  /* [N*3] (z = 0) */
     float *dL_dconic;   /* [N*4] (a, b, 0, c) */
+    /* Optional (view-parallel training, see gsr_sh_grad_from_views): this view's PAYLOAD, [N*3 + 4] floats =
+     * N rows of the colour gradient the SH backward starts from, dL_dcolor * (1 - clamped) (backward.py:88-92; zero for
+     * Gaussians that get no SH gradient), then the camera position (3 floats) and a zero.  When it is given, dL_dshs may
+     * be NULL and the 192-byte-per-Gaussian SH gradient is then not written at all. */
+    float *dL_drgb;     /* [N*3 + 4] or NULL */
 } GsrGrads;
 
 int gsr_abi_version(void);
@@ -185,6 +190,17 @@ typedef struct GsrAdam {
     int32_t iteration;    /* 0-based; bias correction uses iteration + 1 (optimizer.py:47-48) */
 } GsrAdam;
 int gsr_adam_update(const GsrAdam *adam, void *stream);
+
+/* ---- view-parallel gradient exchange -------------------------------------------------
+ * The SH gradient of one view is an outer product: dL_dsh[k] = basis_k(normalize(mean - campos)) * dL_drgb
+ * (backward.py:95-255), so V ranks need not all-reduce 48 floats per Gaussian: they all-gather each view's payload
+ * (GsrGrads.dL_drgb: 3 floats per Gaussian + the camera position) and every rank rebuilds
+ *     dL_dshs[i][k][c] = scale * sum_v basis_k(dir_v(i)) * drgb_v[i][c]       (views summed in order v = 0..V-1)
+ * with the same per-view products the single-view backward forms.  `payloads` is a HOST array of V DEVICE pointers, each
+ * to one [N*3 + 4] payload; coefficients above `sh_degree` are written as zero.  1 <= V <= GSR_MAX_VIEWS. */
+#define GSR_MAX_VIEWS 16
+int gsr_sh_grad_from_views(int64_t N, const float *means, int32_t sh_degree, int32_t V, const float *const *payloads, float scale,
+                           float *dL_dshs /* [N*16*3] out */, void *stream);
 
 /* ---- row f4: adaptive density control --------------------------------
  * Replaces the Warp kernels the reference trainer launches in densification_and_pruning()

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(libpath):
 def test_host_only_entry_points(libpath):
     _lib = sub("_lib")
     L = _lib.lib()
-    assert L.gsr_abi_version() == 1
+    assert L.gsr_abi_version() == 2
     assert _lib.strerror(0) == "ok" and "2^30" in _lib.strerror(_lib.GSR_E_OVERFLOW)
     a, b = L.gsr_geom_workspace_bytes(1000), L.gsr_geom_workspace_bytes(2000)
     assert 0 < a < b and b >= 2000 * (64 + 8 + 8)
@@ -50,7 +50,7 @@ def test_struct_layouts_match_header():
     _lib = sub("_lib")
     assert C.sizeof(_lib.GsrCamera) == (16 + 16 + 3 + 3 + 2 + 2) * 4 + 2 * 4
     assert C.sizeof(_lib.GsrScene) == 8 + 5 * 8 + 3 * 4 + 4   # trailing pad to 8
-    assert C.sizeof(_lib.GsrGeom) == 10 * 8 and C.sizeof(_lib.GsrGrads) == 8 * 8
+    assert C.sizeof(_lib.GsrGeom) == 10 * 8 and C.sizeof(_lib.GsrGrads) == 9 * 8 and C.sizeof(_lib.GsrParams) == 6 * 8
     assert C.sizeof(_lib.GsrBinning) == 24 and C.sizeof(_lib.GsrImage) == 32
     assert _lib.GsrCamera.focal_x.offset == (16 + 16 + 3 + 3 + 2) * 4
 

@@ -30,7 +30,13 @@ def _worker(rank, world, port, q):
     d.reduce_gradients(arena, w, average=True)
     views = d.views_for_rank(8, r, w)
     parts = d.arena_views(arena, n)
-    q.put((r, w, arena[:4].tolist(), float(arena[-1]), views, {k: tuple(v.shape) for k, v in parts.items()}))
+    # factored exchange: the 11-float arena is averaged, every rank ends with every view's payload in rank order
+    small = torch.full((d.SMALL_ARENA_FLOATS * n,), float(rank + 1))
+    payload = torch.arange(3 * n + 4, dtype=torch.float32) + 10000.0 * rank
+    gathered = d.exchange_factored(small, payload, average=True)
+    fact = (tuple(gathered.shape), float(small[0]), float(small[-1]), gathered[:, 0].tolist(), gathered[:, -1].tolist(),
+            {k: tuple(v.shape) for k, v in d.small_arena_views(small, n).items()})
+    q.put((r, w, arena[:4].tolist(), float(arena[-1]), views, {k: tuple(v.shape) for k, v in parts.items()}, fact))
     torch.distributed.destroy_process_group()
 
 
@@ -45,7 +51,10 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r, w, head, tail, views, shapes in res:
+    for r, w, head, tail, views, shapes, fact in res:
+        assert fact[0] == (2, 3004) and fact[1] == 1.5 and fact[2] == 1.5
+        assert fact[3] == [0.0, 10000.0] and fact[4] == [3003.0, 13003.0]
+        assert fact[5] == {"dL_dmean3D": (1000, 3), "dL_dscale": (1000, 3), "dL_drot": (1000, 4), "dL_dopacity": (1000,)}
         assert w == 2
         np.testing.assert_allclose(head, [1.5, 3.0, 4.5, 1.5])    # mean of rank+1 scalings
         assert tail == 1.5
