@@ -1,0 +1,94 @@
+/* gsr_client.c -- a plain C program (gcc, no torch, no Python, no C++) that drives libgsr_hip.so through include/gsr.h:
+ * the drop-in boundary is a C ABI over caller-owned device memory and this is the proof.  It reads one scene + camera +
+ * dL/dpixels from a flat binary file, runs gsr_forward_count / gsr_forward_render / gsr_backward with buffers it allocates
+ * with hipMalloc, and writes every output to a flat binary file; tests/test_gpu_c_abi.py compares that file with the CPU
+ * oracle under the tolerances of tests/parity.py.
+ *
+ * input : int64 N, int32 W, H, degree, 3 x int32 pad; GsrCamera (raw struct); float means[3N], scales[3N], rots[4N],
+ *         opacity[N], sh[48N], dpix[3WH]
+ * output: int64 D; int32 radii[N], offsets[N]; float xy[2N], depths[N], cov3D[6N], rgb[3N], conic[4N], clamped[3N];
+ *         int32 point_list[D], ranges[2T]; float image[3WH], inv_depth[WH], final_T[WH]; int32 n_contrib[WH];
+ *         float dmean3D[3N], dscale[3N], drot[4N], dopacity[N], dshs[48N], dcolor[3N], dmean2D[3N], dconic[4N] */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "gsr.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d HIP error %d\n", __FILE__, __LINE__, (int)e_); return 2; } } while (0)
+#define CHECK_GSR(x) do { int r_ = (x); if (r_ != GSR_OK) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, gsr_strerror(r_)); return 3; } } while (0)
+
+static void *dev_alloc(size_t bytes) { void *p = NULL; return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? p : NULL; }
+static void *dev_upload(FILE *f, size_t bytes)
+{
+    void *h = malloc(bytes ? bytes : 4), *d = dev_alloc(bytes);
+    if (!h || !d || (bytes && fread(h, 1, bytes, f) != bytes)) { fprintf(stderr, "short read\n"); exit(4); }
+    if (hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) exit(5);
+    free(h);
+    return d;
+}
+static void dump(FILE *f, const void *d, size_t bytes)
+{
+    void *h = malloc(bytes ? bytes : 4);
+    if (bytes && hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) exit(6);
+    fwrite(h, 1, bytes, f);
+    free(h);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 1; }
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) return 1;
+    int64_t N; int32_t hdr[6]; GsrCamera cam;
+    if (fread(&N, 8, 1, in) != 1 || fread(hdr, 4, 6, in) != 6 || fread(&cam, sizeof cam, 1, in) != 1) return 4;
+    const int32_t W = hdr[0], H = hdr[1], degree = hdr[2];
+    const size_t P = (size_t)W * H, n = (size_t)N;
+    const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
+    if (gsr_abi_version() != GSR_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+
+    GsrScene sc = {N, 0, 0, 0, 0, 0, degree, 1.0f, 1};
+    sc.means = dev_upload(in, 12 * n); sc.scales = dev_upload(in, 12 * n); sc.rotations = dev_upload(in, 16 * n);
+    sc.opacity = dev_upload(in, 4 * n); sc.sh = dev_upload(in, 192 * n);
+    float *dpix = dev_upload(in, 12 * P);
+    fclose(in);
+
+    hipStream_t stream;
+    CHECK_HIP(hipStreamCreate(&stream));
+    GsrGeom g = {0};
+    g.radii = dev_alloc(4 * n); g.tiles_touched = dev_alloc(4 * n); g.point_offsets = dev_alloc(4 * n); g.xy = dev_alloc(8 * n);
+    g.depths = dev_alloc(4 * n); g.cov3D = dev_alloc(24 * n); g.rgb = dev_alloc(12 * n); g.conic_opacity = dev_alloc(16 * n);
+    g.clamped_state = dev_alloc(12 * n);
+    const size_t geom_bytes = gsr_geom_workspace_bytes(N);
+    void *geom_ws = dev_alloc(geom_bytes);
+    int64_t D = -1;
+    CHECK_GSR(gsr_forward_count(&sc, &cam, &g, geom_ws, geom_bytes, &D, stream));
+
+    GsrBinning bin = {D, dev_alloc(4 * (size_t)D), dev_alloc(8 * (size_t)tiles)};
+    GsrImage img = {dev_alloc(12 * P), dev_alloc(4 * P), dev_alloc(4 * P), dev_alloc(4 * P)};
+    const size_t bin_bytes = gsr_binning_workspace_bytes(N, D, W, H);
+    void *bin_ws = dev_alloc(bin_bytes);
+    CHECK_GSR(gsr_forward_render(&sc, &cam, &g, &bin, &img, geom_ws, geom_bytes, bin_ws, bin_bytes, stream));
+
+    GsrGrads gr = {dev_alloc(12 * n), dev_alloc(12 * n), dev_alloc(16 * n), dev_alloc(4 * n), dev_alloc(192 * n), dev_alloc(12 * n),
+                   dev_alloc(12 * n), dev_alloc(16 * n), NULL};
+    const size_t bwd_bytes = gsr_backward_workspace_bytes(N, D, W, H);
+    void *bwd_ws = dev_alloc(bwd_bytes);
+    g.blend_records = geom_ws; /* still untouched: the backward reuses the forward's records */
+    CHECK_GSR(gsr_backward(&sc, &cam, &g, &bin, &img, dpix, &gr, bwd_ws, bwd_bytes, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+
+    FILE *out = fopen(argv[2], "wb");
+    if (!out) return 1;
+    fwrite(&D, 8, 1, out);
+    dump(out, g.radii, 4 * n); dump(out, g.point_offsets, 4 * n); dump(out, g.xy, 8 * n); dump(out, g.depths, 4 * n);
+    dump(out, g.cov3D, 24 * n); dump(out, g.rgb, 12 * n); dump(out, g.conic_opacity, 16 * n); dump(out, g.clamped_state, 12 * n);
+    dump(out, bin.point_list, 4 * (size_t)D); dump(out, bin.ranges, 8 * (size_t)tiles);
+    dump(out, img.image, 12 * P); dump(out, img.inv_depth, 4 * P); dump(out, img.final_T, 4 * P); dump(out, img.n_contrib, 4 * P);
+    dump(out, gr.dL_dmean3D, 12 * n); dump(out, gr.dL_dscale, 12 * n); dump(out, gr.dL_drot, 16 * n); dump(out, gr.dL_dopacity, 4 * n);
+    dump(out, gr.dL_dshs, 192 * n); dump(out, gr.dL_dcolor, 12 * n); dump(out, gr.dL_dmean2D, 12 * n); dump(out, gr.dL_dconic, 16 * n);
+    fclose(out);
+    printf("gsr_client ok: N=%lld D=%lld %dx%d\n", (long long)N, (long long)D, W, H);
+    return 0;
+}

@@ -141,3 +141,14 @@ def test_lr_scheduler_matches_the_reference_formula():
     assert abs(sch.get_lr(6999, 7000) - 1e-4) < 1e-12
     assert abs(sch.get_lr(3500, 7001) - 1e-3) < 1e-9        # geometric midpoint
     assert sch.get_lr(10 ** 6, 7000) == sch.get_lr(6999, 7000) and sch.get_lr(5, 1) == 1e-2
+
+
+def test_header_is_plain_c_and_client_links(tmp_path):
+    """include/gsr.h must compile as C11 (it is the boundary a non-C++ host binds), and the plain-C client of
+    tests/c_abi must link against the library with nothing but the HIP runtime."""
+    import subprocess
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "gsr.h"\nint main(void) { GsrScene s; GsrParams p; (void)s; (void)p; return GSR_ABI_VERSION == 2 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)])
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "tests", "c_abi")])
+    assert os.path.exists(os.path.join(ROOT, "tests", "c_abi", "gsr_client"))
