@@ -1,7 +1,7 @@
 // blend_bwd_splat.hip -- Gaussian-parallel gradient replay for gfx950 (default backward blend).
 //
 // Same mathematics as the reference's wp_render_backward_kernel (backward.py:559-706), parallelised
-// the other way round.  The reference (and blend_bwd.hip) gives a lane a PIXEL and walks the list, so
+// the other way round.  The reference (and this library's first version) gives a lane a PIXEL and walks the list, so
 // every (pixel, entry) pair produces nine values that must be summed over pixels.  Here a lane owns a
 // list ENTRY and the wave walks the pixels, so the nine gradients of an entry accumulate in that
 // lane's registers with no cross-lane reduction at all; what crosses lanes instead is the per-pixel

@@ -5,9 +5,12 @@
 // is the list ordered by (tile, depth bits, id) -- ties broken by id because the sort is stable and
 // pairs are emitted in id order (quirk Q13).  We produce the SAME list with much less HBM traffic:
 //   1. sort the N Gaussians once by depth bits (stable, from id order)      -> order (depth, id)
-//   2. expand them to (tile << 32 | id) items in that order                  -> order (depth, id) per tile
-//   3. stable-partition the D items by tile id only (ceil(log2(tiles)/8) passes instead of 8)
-// All sorting is one kernel family: a stable LSD radix pass over 64-bit items on an 8-bit digit.
+//   2. expand them to (tile << id_shift | id) items in that order            -> order (depth, id) per tile
+//      (32-bit items when tile bits + id bits <= 32, else 64-bit with id_shift = 32)
+//   3. stable-partition the D items by tile id only (ceil(log2(tiles)/8) passes instead of 8, digit bits split
+//      evenly: 12 tile bits -> 6 + 6)
+// All sorting is one kernel family: a stable LSD radix pass over 32- or 64-bit items on a 4..8-bit digit.
+// The last pass of the depth sort also carries each Gaussian's tile rectangle and tile count to its sorted position.
 // Wave64 ballots give each item its rank among equal digits (no per-item atomics), an LDS reorder
 // makes the scatter write contiguous runs.  No inter-workgroup spin-waits anywhere: every dependency
 // is a kernel boundary.  (A single-kernel-per-pass variant with ticketed chunks and decoupled look-back
