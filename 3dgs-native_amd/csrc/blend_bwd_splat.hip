@@ -20,8 +20,8 @@
 // lanes write one 64-byte GradRec with float atomics (4 whole 64-B requests per wave instruction).
 //
 // Differences from the reference in float rounding only: sums over pixels/entries are re-associated
-// (quirk Q15), per-entry constants are factored out of the pixel sums, FMA contraction is on, and 1/x
-// uses v_rcp_f32 (1 ulp).
+// (quirk Q15), per-entry constants are factored out of the pixel sums, FMA contraction is on (except in `power`, which is
+// evaluated in the forward's operation order so the replayed alphas are the forward's), and 1/x uses v_rcp_f32 (1 ulp).
 #include "gsr_internal.h"
 
 // This kernel re-associates float sums anyway (quirk Q15), so fused multiply-adds are allowed here.
@@ -101,6 +101,17 @@ __device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, floa
     }
     return qmin <= tau * 1.0001f + 1e-3f;
 }
+
+// power = -0.5 (a dx^2 + c dy^2) - b dx dy in the forward's (= the reference's, forward.py:477-479 / backward.py:641-643)
+// operation order, every product rounded on its own.  For needle-like splats (100:1 and more, hundreds of pixels long) the
+// three terms cancel to a few units out of 1e4..1e6, and a fused form replays alphas that differ from the forward's by
+// per cent: tests/test_gpu_fuzz.py seed 63 had dL_dconic 3.5 % off for a 1.28 x 0.008 x 0.003 Gaussian.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float power_ref_order(float ca, float cb, float cc, float dx, float dy)
+{
+    return -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+}
+#pragma clang fp contract(fast)
 
 constexpr int QCAP = 128; // ring of compacted entries (power of two, >= 2*64 - 1)
 
@@ -204,7 +215,6 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         //   Sxx = sum h dx^2         Sxy = sum h dx dy  Syy = sum h dy^2      Sop = sum G dL/dalpha
         float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, S1 = 0.f, S2 = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sop = 0.f;
         bool touched = false;
-        const float na = -0.5f * a.z, nc = -0.5f * b.x, nb = -a.w;
 
         for (int q = 0; q < ((dbg & 2) ? 1 : NPIX); ++q) {
             const float4 pb = s_pb[q];
@@ -213,8 +223,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const float4 pa = s_pa[q];
             const float2 carry = s_carry[q];
             const float d_x = a.x - pa.x, d_y = a.y - pa.y;
-            // power = -0.5 (a dx^2 + c dy^2) - b dx dy, contracted (this file allows FMA)
-            const float power = d_x * (na * d_x + nb * d_y) + nc * d_y * d_y;
+            const float power = power_ref_order(a.z, a.w, b.x, d_x, d_y);
             const float G = fast_exp(power);
             const float alpha = fminf(0.99f, b.y * G);
             const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));

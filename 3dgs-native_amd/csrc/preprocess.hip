@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
 
     sh_rows_commit(sh_regs, lds_wave, lane);
-    const unsigned long long late_mask = (dbg & 4) ? 0ull : (__ballot(need_sh) & ~early_mask);
+    // in_range: tail lanes redo the last Gaussian; their rows do not exist (found by tests/test_gpu_fuzz.py: N = 1, one big
+    // splat centred outside the frustum -> 63 rows read past the end of the SH array)
+    const unsigned long long late_mask = (dbg & 4) ? 0ull : (__ballot(need_sh && in_range) & ~early_mask);
     if (late_mask) { // wave-uniform and rare
         sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, late_mask);
         sh_rows_commit_masked(sh_regs, lds_wave, lane, late_mask);

