@@ -166,3 +166,26 @@ def test_error_paths():
     assert total == 0 and prefix.numel() == 0
     model = dz.GaussianModel(empty)
     assert model.densification_and_pruning(600)["prune_skipped"]
+
+
+def test_trainer_sequence_sweep():
+    """Seeded sweep of the whole density-control sequence against the oracle: row counts at wave / scan-unit edges,
+    thresholds that flag nothing / everything / the last row, every branch of the prune gate."""
+    import torch
+    dz = sub("densify")
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n = int(rng.choice([1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 2049, 5000, 12345]))
+        p, g = make_params(n, seed=7000 + case, big_frac=float(rng.choice([0.0, 0.3, 1.0])))
+        cfg = {"densify_grad_threshold": float(rng.choice([0.0, 2e-4, 4e-4, 1.0])), "percent_dense": float(rng.choice([0.0, 0.01, 1.0])),
+               "cull_opacity_threshold": float(rng.choice([0.0, 0.005, 0.5, 2.0])), "min_valid_points": int(rng.choice([0, 1000])),
+               "max_allowed_prune_ratio": float(rng.choice([0.05, 0.5, 1.0])), "max_valid_points": int(rng.choice([1500, 1000000]))}
+        if case % 5 == 0:
+            g[-1] = 1.0                                            # the last row always flagged: its flag is not counted (Q17)
+        it = int(rng.choice([600, 3000, 650]))
+        model = dz.GaussianModel(to_dev(p), config=cfg, scene_extent=float(rng.choice([1.0, 4.0])))
+        model.grads["positions"].copy_(torch.as_tensor(g))
+        log = model.densification_and_pruning(it)
+        ref, ref_log = od.densification_and_pruning(p, g, it, dict({"background_color": [0.0, 0.0, 0.0]}, **cfg), model.scene_extent)
+        assert log == ref_log, (case, n, cfg, log, ref_log)
+        assert_params_equal(model.params, ref)

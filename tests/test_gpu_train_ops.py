@@ -90,3 +90,31 @@ def test_training_iterations_reduce_the_loss(cameras, scenes):
     # lr_sh = 2e-3 (reference config.py:40) moves colours slowly: 25 steps took 0.1155 -> 0.0897 when written
     assert losses[-1] < 0.85 * losses[0], losses
     assert all(b < a for a, b in zip(losses, losses[1:])), losses
+
+
+def test_l1_and_adam_size_sweep(oracle):
+    """Odd sizes (float4 tails, partial waves) for the two flat kernels."""
+    import torch
+    gsr = pkg()
+    rng = np.random.default_rng(77)
+    for (H, W) in [(1, 1), (1, 5), (3, 7), (17, 33), (2, 2), (31, 1)]:
+        r = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+        t = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+        got_loss = gsr.loss.l1_loss(torch.as_tensor(r).cuda(), t)
+        assert abs(got_loss - oracle.l1_loss(r, t)) <= 2e-5 * max(1e-6, oracle.l1_loss(r, t))
+        np.testing.assert_array_equal(gsr.loss.compute_image_gradients(r, t, lambda_dssim=0.0).cpu().numpy(),
+                                      oracle.compute_image_gradients(r, t, lambda_dssim=0.0))
+    for n in [1, 2, 63, 65, 257, 1000]:
+        shapes = {"positions": (n, 3), "scales": (n, 3), "rotations": (n, 4), "opacities": (n,), "shs": (n * 16, 3)}
+        P = {k: rng.normal(0, 1, s).astype(np.float32) for k, s in shapes.items()}
+        G = {k: rng.normal(0, 1e-2, s).astype(np.float32) for k, s in shapes.items()}
+        M = {k: rng.normal(0, 1e-3, s).astype(np.float32) for k, s in shapes.items()}
+        V = {k: rng.uniform(0, 1e-4, s).astype(np.float32) for k, s in shapes.items()}
+        d = lambda D: {k: torch.as_tensor(v).cuda() for k, v in D.items()}
+        dP, dG, dM, dV = d(P), d(G), d(M), d(V)
+        gsr.optimizer.adam_update(dP, dG, dM, dV, iteration=41)
+        oracle.adam_update(P, G, M, V, gsr.optimizer.DEFAULT_LR, iteration=41)      # in place
+        for k in shapes:
+            np.testing.assert_allclose(dP[k].cpu().numpy(), P[k], rtol=2e-6, atol=1e-7, err_msg=f"param {k} n={n}")
+            np.testing.assert_allclose(dM[k].cpu().numpy(), M[k], rtol=2e-6, atol=1e-9, err_msg=f"m {k} n={n}")
+            np.testing.assert_allclose(dV[k].cpu().numpy(), V[k], rtol=2e-6, atol=1e-12, err_msg=f"v {k} n={n}")
