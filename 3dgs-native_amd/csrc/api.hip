@@ -275,7 +275,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const int tb = tile_bits(tiles);
     int id_bits = 1;
     while ((1LL << id_bits) < N) ++id_bits;
-    const bool narrow = tb + id_bits <= 32;
+    const bool narrow = tb + id_bits <= 32 && !(gsr_debug_flags & 32); // GSR_DEBUG bit 5: 64-bit tile items at any size (tests)
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
     HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, s));
     mark(st, 6, s);

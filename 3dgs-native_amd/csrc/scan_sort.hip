@@ -427,7 +427,7 @@ template <int BITS, typename ItemT>
 static void radix_pass_bits(const ItemT *in, ItemT *out, int32_t *hist, int32_t *totals, int64_t n, int shift, hipStream_t s)
 {
     constexpr int RADIX = 1 << BITS;
-    if (n <= GSR_RADIX_SMALL_N) {
+    if (n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64)) { // GSR_DEBUG bit 6: take the large-n path at any n (tests)
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
@@ -471,7 +471,7 @@ hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t
 {
     if (n <= 0) return hipSuccess;
     const ScatterCarry carry{rect, rect_sorted, cnt_sorted};
-    if (n <= GSR_RADIX_SMALL_N) {
+    if (n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64)) { // GSR_DEBUG bit 6: take the large-n path at any n (tests)
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
