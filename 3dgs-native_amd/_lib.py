@@ -70,6 +70,9 @@ EXPORTS = {
                                      C.POINTER(GsrImage), vp, C.c_size_t, vp, C.c_size_t, vp]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
                                C.POINTER(GsrImage), vp, C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
+    "gsr_backward_blend": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
+                                     C.POINTER(GsrImage), vp, vp, vp, C.c_size_t, vp]),
+    "gsr_backward_geom": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrGrads), vp, C.c_size_t, vp]),
     "gsr_l1_loss_grad": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
     "gsr_adam_update": (C.c_int, [C.POINTER(GsrAdam), vp]),
     "gsr_sh_grad_from_views": (C.c_int, [C.c_int64, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_float, vp, vp]),

@@ -10,7 +10,8 @@ One keyword beyond the reference's: `sh_gradient="factored"` (view-parallel trai
 gradient unwritten and returns instead the 3-float colour gradient it is an outer product of, as a self-contained view
 payload (`_view_payload`: N rows, then the camera position); `_arena` is then the 11 floats mean3D | scale | rot | opacity
 and `dL_dshs` is None until `dist.sh_gradients_from_views` rebuilds it from all views' payloads ("both" returns the dense
-arena and the payload of the same call).
+arena and the payload of the same call).  `on_payload(payload)` is called as soon as the payload is complete -- after the
+blend half, before the per-Gaussian half -- so an exchange can start early (dist.FactoredExchange).
 """
 import ctypes as C
 
@@ -43,7 +44,7 @@ def _get(buf, key):
 def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=None, rotations=None, scale_modifier=1.0,
              viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5, image_height=256, image_width=256, campos=None,
              radii=None, means2D=None, conic_opacity=None, rgb=None, clamped=None, cov3Ds=None, geom_buffer=None,
-             binning_buffer=None, img_buffer=None, degree=3, debug=False, *, sh_gradient="dense"):
+             binning_buffer=None, img_buffer=None, degree=3, debug=False, *, sh_gradient="dense", on_payload=None):
     if sh_gradient not in ("dense", "factored", "both"):
         raise ValueError("sh_gradient must be 'dense', 'factored' or 'both'")
     factored = sh_gradient == "factored"
@@ -111,8 +112,18 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
                           _host.ptr(dL_dsh), _host.ptr(dL_dcolor), _host.ptr(dL_dmean2D), _host.ptr(dL_dconic), _host.ptr(payload))
     with torch.cuda.device(dev):
         ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
-        _lib.check(L.gsr_backward(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
-                                  C.byref(grads), _host.ptr(ws), ws.numel(), _host.stream_ptr(dev)))
+        if on_payload is not None and payload is not None:
+            # two halves: the view payload is complete after the blend half, so the caller's hook can start its exchange
+            # (an asynchronous all-gather) while the per-Gaussian half still runs
+            _lib.check(L.gsr_backward_blend(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
+                                            _host.ptr(payload), _host.ptr(ws), ws.numel(), _host.stream_ptr(dev)))
+            on_payload(payload)
+            grads.dL_drgb = None
+            _lib.check(L.gsr_backward_geom(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(grads), _host.ptr(ws), ws.numel(),
+                                           _host.stream_ptr(dev)))
+        else:
+            _lib.check(L.gsr_backward(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
+                                      C.byref(grads), _host.ptr(ws), ws.numel(), _host.stream_ptr(dev)))
     return {
         "dL_dmean3D": dL_dmean3D, "dL_dcolor": dL_dcolor, "dL_dshs": dL_dsh, "dL_dopacity": dL_dopacity,
         "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,

@@ -111,7 +111,7 @@ struct StageTimer {
     bool on = false;
     int max_steps = 0, fwd_step = 0, bwd_step = 0; // recorded (sampled) steps so far
     int every = 1, fwd_calls = 0, bwd_calls = 0;    // record one call in `every`; event records cost ~3 us each
-    bool fwd_sampled = false;
+    bool fwd_sampled = false, split_sampled = false;
     hipEvent_t *ev = nullptr; // [max_steps][GSR_NSTAGES + 3]
     static constexpr int PER = GSR_NSTAGES + 3;
     hipEvent_t &at(int step, int k) { return ev[(size_t)step * PER + k]; }
@@ -299,27 +299,19 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     return GSR_OK;
 }
 
-int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning, const GsrImage *image,
-                 const float *dL_dpixels, const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream)
+// first half: accumulator clear, record (re)pack, blend backward, optional view payload
+static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning,
+                               const GsrImage *image, const float *dL_dpixels, float *payload, void *ws, size_t ws_bytes, hipStream_t s, int st)
 {
-    read_tuning();
-    if (int rc = check_scene_cam(scene, camera)) return rc;
     const int64_t N = scene->N;
-    if (N == 0) return GSR_OK;
-    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || (!grads->dL_dshs && !grads->dL_drgb) ||
-        !grads->dL_dcolor || !grads->dL_dmean2D || !grads->dL_dconic)
-        return GSR_E_NULL;
     if (!geom || !geom->radii || !geom->xy || !geom->cov3D || !geom->rgb || !geom->conic_opacity || !geom->clamped_state) return GSR_E_NULL;
     if (!binning || !image || !dL_dpixels) return GSR_E_NULL;
     const int64_t D = binning->D;
     if (D < 0 || D > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
     if (D > 0 && (!binning->point_list || !binning->ranges || !image->final_T || !image->n_contrib)) return GSR_E_NULL;
     if (!ws || ws_bytes < gsr_backward_workspace_bytes(N, D, camera->W, camera->H)) return GSR_E_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     const CamK cam = make_cam(camera);
     const BwdWs bw = carve_bwd(ws, N);
-    const bool bwd_sampled = g_timer.on && (g_timer.bwd_calls++ % g_timer.every) == 0;
-    const int st = bwd_sampled ? g_timer.bwd_step : -1;
     mark(st, 10, s);
     HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
     const BlendRec *records = (const BlendRec *)geom->blend_records;
@@ -330,9 +322,68 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     mark(st, 11, s);
     if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
     mark(st, 12, s);
+    if (payload) HIP_TRY(gsr_launch_view_payload(*scene, cam, *geom, bw.acc, payload, s));
+    return GSR_OK;
+}
+
+// second half: the four per-Gaussian kernels of backward_preprocess, fused
+static int backward_geom_impl(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrGrads *grads, void *ws,
+                              size_t ws_bytes, hipStream_t s, int st)
+{
+    const int64_t N = scene->N;
+    // dL_dshs and dL_drgb may both be NULL here: the payload was taken from the blend half and the SH gradient is rebuilt later
+    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || !grads->dL_dcolor ||
+        !grads->dL_dmean2D || !grads->dL_dconic)
+        return GSR_E_NULL;
+    if (!geom || !geom->radii || !geom->cov3D || !geom->clamped_state) return GSR_E_NULL;
+    if (!ws || ws_bytes < gsr_backward_workspace_bytes(N, 0, camera->W, camera->H)) return GSR_E_WORKSPACE;
+    const CamK cam = make_cam(camera);
+    const BwdWs bw = carve_bwd(ws, N);
     HIP_TRY(gsr_launch_geom_backward(*scene, cam, *geom, bw.acc, *grads, s));
     mark(st, 13, s);
+    return GSR_OK;
+}
+
+int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning, const GsrImage *image,
+                 const float *dL_dpixels, const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream)
+{
+    read_tuning();
+    if (int rc = check_scene_cam(scene, camera)) return rc;
+    if (scene->N == 0) return GSR_OK;
+    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || (!grads->dL_dshs && !grads->dL_drgb) ||
+        !grads->dL_dcolor || !grads->dL_dmean2D || !grads->dL_dconic)
+        return GSR_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool bwd_sampled = g_timer.on && (g_timer.bwd_calls++ % g_timer.every) == 0;
+    const int st = bwd_sampled ? g_timer.bwd_step : -1;
+    if (int rc = backward_blend_impl(scene, camera, geom, binning, image, dL_dpixels, nullptr, ws, ws_bytes, s, st)) return rc;
+    if (int rc = backward_geom_impl(scene, camera, geom, grads, ws, ws_bytes, s, st)) return rc;
     if (bwd_sampled) ++g_timer.bwd_step;
+    return GSR_OK;
+}
+
+int gsr_backward_blend(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning, const GsrImage *image,
+                       const float *dL_dpixels, float *payload, void *ws, size_t ws_bytes, void *stream)
+{
+    read_tuning();
+    if (int rc = check_scene_cam(scene, camera)) return rc;
+    if (scene->N == 0) return GSR_OK;
+    // stage events: the two halves of one backward share a record; it is opened here and closed by gsr_backward_geom
+    g_timer.split_sampled = g_timer.on && (g_timer.bwd_calls++ % g_timer.every) == 0;
+    return backward_blend_impl(scene, camera, geom, binning, image, dL_dpixels, payload, ws, ws_bytes, (hipStream_t)stream,
+                               g_timer.split_sampled ? g_timer.bwd_step : -1);
+}
+
+int gsr_backward_geom(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrGrads *grads, void *ws, size_t ws_bytes,
+                      void *stream)
+{
+    read_tuning();
+    if (int rc = check_scene_cam(scene, camera)) return rc;
+    if (scene->N == 0) return GSR_OK;
+    const bool sampled = g_timer.split_sampled;
+    g_timer.split_sampled = false;
+    if (int rc = backward_geom_impl(scene, camera, geom, grads, ws, ws_bytes, (hipStream_t)stream, sampled ? g_timer.bwd_step : -1)) return rc;
+    if (sampled) ++g_timer.bwd_step;
     return GSR_OK;
 }
 

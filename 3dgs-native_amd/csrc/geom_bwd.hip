@@ -329,6 +329,30 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     if (dL_dshs && rows_valid > 0) sh_rows_store(reinterpret_cast<float4 *>(dL_dshs) + wave_row0 * 12, lds_wave, lane, rows_valid);
 }
 
+// ---- the view payload on its own (gsr_backward_blend): what geom_backward_kernel writes to dL_drgb, from the same inputs
+// with the same expressions, so the exchange can start before the per-Gaussian half runs ----
+__global__ __launch_bounds__(256) void view_payload_kernel(int64_t N, const float *__restrict__ means, CamK cam, const int32_t *__restrict__ radii,
+                                                           const float *__restrict__ clamped_state, const GradRec *__restrict__ acc,
+                                                           float *__restrict__ payload)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N) return;
+    float o_rgb[3] = {0.f, 0.f, 0.f};
+    if (radii[idx] > 0) {
+        const float mean[3] = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+        const float dir_orig[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
+        const float dir_len = sqrtf(dot3(dir_orig, dir_orig));
+        if (!(dir_len < 1e-8f)) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(acc + idx);
+            const float g_col[3] = {a0.x, a0.y, a0.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o_rgb[c] = g_col[c] * (1.0f + (-1.0f * clamped_state[3 * idx + c]));
+        }
+    }
+    payload[3 * idx] = o_rgb[0]; payload[3 * idx + 1] = o_rgb[1]; payload[3 * idx + 2] = o_rgb[2];
+    if (idx == 0) { payload[3 * N] = cam.campos[0]; payload[3 * N + 1] = cam.campos[1]; payload[3 * N + 2] = cam.campos[2]; payload[3 * N + 3] = 0.0f; }
+}
+
 // ---- SH gradient rebuilt from V views' colour gradients (gsr_sh_grad_from_views) ----
 // One lane per Gaussian: per view it normalises the direction once, forms the 16 basis values with the expressions (and
 // rounding) of the single-view kernel above, and adds basis_k * drgb_c into 48 accumulators; the finished row goes out
@@ -409,6 +433,14 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
     hipLaunchKernelGGL(geom_backward_kernel, dim3((unsigned)gsr_div_up(sc.N, 256)), dim3(256), 0, s, sc.N, sc.means, sc.scales,
                        sc.rotations, sc.sh, sc.sh_degree, cam, h_x, h_y, g.radii, g.cov3D, g.clamped_state, acc, gr.dL_dmean3D,
                        gr.dL_dscale, gr.dL_drot, gr.dL_dopacity, gr.dL_dshs, gr.dL_dcolor, gr.dL_dmean2D, gr.dL_dconic, gr.dL_drgb);
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s)
+{
+    if (sc.N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(view_payload_kernel, dim3((unsigned)gsr_div_up(sc.N, 256)), dim3(256), 0, s, sc.N, sc.means, cam, g.radii, g.clamped_state,
+                       acc, payload);
     return hipGetLastError();
 }
 

@@ -88,6 +88,7 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
                                     const GsrGrads &gr, hipStream_t s);
 
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
+hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
 extern int gsr_debug_flags;        // GSR_DEBUG    : bits 0-3 timing ablations (wrong results); bit 5 forces 64-bit tile items, bit 6 the
                                    //                large-n radix chunks (same results: tests/test_gpu_alt_paths.py); never set in production
 extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)

@@ -90,6 +90,54 @@ def exchange_factored(arena, payload, average=True):
     return gathered
 
 
+class FactoredExchange:
+    """The factored exchange with its collectives overlapped with compute (one view per rank per step):
+
+        ex = FactoredExchange()
+        g = backward(..., sh_gradient="factored", on_payload=ex.start_gather)   # all-gather runs beside the per-Gaussian half
+        grads = ex.finish(g, means3D, degree)                                   # all-reduce runs beside the SH rebuild
+
+    RCCL executes the two collectives in issue order on its own stream: the all-gather of the payloads (known after the blend
+    half of the backward) overlaps `geom_backward_kernel`; the all-reduce of the 11-float arena (known after it) overlaps the
+    rebuild kernel, which needs only the gathered payloads.  Single process: no collectives, same results."""
+
+    def __init__(self):
+        self._gathered = None
+        self._work = None
+
+    def start_gather(self, payload):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            self._gathered, self._work = payload.unsqueeze(0), None
+            return
+        world = dist.get_world_size()
+        self._gathered = torch.empty((world, payload.numel()), dtype=payload.dtype, device=payload.device)
+        if dist.get_backend() == "nccl":
+            self._work = dist.all_gather_into_tensor(self._gathered.view(-1), payload, async_op=True)
+        else:
+            self._work = dist.all_gather([self._gathered[v] for v in range(world)], payload, async_op=True)
+
+    def finish(self, grads, means3D, degree=3, average=True, out=None):
+        """Returns the dict of the five averaged (or summed) optimizer gradients."""
+        arena = grads["_arena"]
+        n = arena.numel() // SMALL_ARENA_FLOATS
+        reduce_work = None
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if average and arena.is_cuda and dist.get_backend() == "nccl":
+                reduce_work = dist.all_reduce(arena, op=dist.ReduceOp.AVG, async_op=True)
+            else:
+                reduce_work = dist.all_reduce(arena, op=dist.ReduceOp.SUM, async_op=True)
+        if self._work is not None:
+            self._work.wait()
+        res = {"dL_dshs": sh_gradients_from_views(means3D, self._gathered, degree, average=average, out=out)}
+        if reduce_work is not None:
+            reduce_work.wait()
+            if average and not (arena.is_cuda and dist.get_backend() == "nccl"):
+                arena.mul_(1.0 / dist.get_world_size())
+        res.update(small_arena_views(arena, n))
+        self._gathered = self._work = None
+        return res
+
+
 def sh_gradients_from_views(means3D, payloads, degree=3, average=True, out=None, scale=None):
     """dL_dshs [N*16, 3] summed (or averaged) over the views whose payloads are the rows of `payloads` ([V, 3*N + 4]) --
     the HIP kernel behind gsr_sh_grad_from_views.  `payloads` may also be a list of V separate [3*N + 4] tensors.

@@ -106,9 +106,11 @@ def main():
                prefiltered=False, antialiasing=False, clamped=True)
 
     sh_out = torch.empty((N * 16, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    exchange = gsr.dist.FactoredExchange()
 
     def step():
         img, depth, buf = gsr.render_gaussians(**fkw)
+        factored = world > 1 and not args.dense_exchange
         grads = gsr.backward(
             background=bg, means3D=means, dL_dpixels=dpix, opacity=opac, shs=shs, scales=scales, rotations=rots,
             scale_modifier=1.0, viewmatrix=fkw["viewmatrix"], projmatrix=fkw["projmatrix"], tan_fovx=fkw["tan_fovx"],
@@ -116,11 +118,11 @@ def main():
             means2D=buf["points_xy_image"], conic_opacity=buf["conic_opacity"], rgb=buf["colors"], cov3Ds=buf["cov3Ds"],
             clamped=buf["clamped_state"], geom_buffer=None, binning_buffer={"point_list": buf["point_list"]},
             img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]}, degree=3,
-            sh_gradient="factored" if (world > 1 and not args.dense_exchange) else "dense")
-        if world > 1 and not args.dense_exchange:
-            # factored exchange: all-reduce 11 floats per Gaussian, all-gather 3, rebuild the averaged SH gradient locally
-            gathered = gsr.dist.exchange_factored(grads["_arena"], grads["_view_payload"])
-            grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(means, gathered, 3, average=True, out=sh_out)
+            sh_gradient="factored" if factored else "dense", on_payload=exchange.start_gather if factored else None)
+        if factored:
+            # all-reduce 11 floats per Gaussian, all-gather 3 (started inside backward, beside its per-Gaussian half), rebuild
+            # the averaged SH gradient locally (beside the all-reduce)
+            grads.update(exchange.finish(grads, means, 3, average=True, out=sh_out))
         elif world > 1:
             gsr.dist.reduce_gradients(grads["_arena"], world)
         return buf, grads

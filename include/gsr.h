@@ -160,6 +160,16 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
                  const GsrBinning *binning, const GsrImage *image, const float *dL_dpixels,
                  const GsrGrads *grads, void *ws, size_t ws_bytes, void *stream);
 
+/* The same in two halves, for a caller that wants to start exchanging the view payload (GsrGrads.dL_drgb) while the
+ * per-Gaussian half still runs: gsr_backward_blend = backward_render (backward.py:890-953) and, if `payload` is not
+ * NULL, the [N*3 + 4] view payload; gsr_backward_geom = backward_preprocess (backward.py:770-888) from the accumulators
+ * the first half left in `ws` (same ws, unmodified in between; grads->dL_dshs and grads->dL_drgb may both be NULL when the
+ * payload was taken from the first half).  gsr_backward(...) == blend(payload = NULL) + geom. */
+int gsr_backward_blend(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrBinning *binning,
+                       const GsrImage *image, const float *dL_dpixels, float *payload, void *ws, size_t ws_bytes, void *stream);
+int gsr_backward_geom(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrGrads *grads, void *ws,
+                      size_t ws_bytes, void *stream);
+
 /* ---- "next" rows of SURVEY.md section 8(f): the steps either side of the rasterizer in a training iteration ----
  *
  * f2  L1 loss + pixel gradient (reference loss.py: l1_loss :148-176 -> l1_loss_kernel :12-31;

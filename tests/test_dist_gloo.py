@@ -36,7 +36,15 @@ def _worker(rank, world, port, q):
     gathered = d.exchange_factored(small, payload, average=True)
     fact = (tuple(gathered.shape), float(small[0]), float(small[-1]), gathered[:, 0].tolist(), gathered[:, -1].tolist(),
             {k: tuple(v.shape) for k, v in d.small_arena_views(small, n).items()})
-    q.put((r, w, arena[:4].tolist(), float(arena[-1]), views, {k: tuple(v.shape) for k, v in parts.items()}, fact))
+    # the overlapped form: async gather started first, async reduce inside finish(); the HIP rebuild is replaced by a probe
+    small2 = torch.full((d.SMALL_ARENA_FLOATS * n,), float(rank + 1))
+    ex = d.FactoredExchange()
+    ex.start_gather(payload)
+    probe = {}
+    d.sh_gradients_from_views = lambda means, gathered, degree, average=True, out=None: probe.setdefault("g", gathered.clone())
+    res = ex.finish({"_arena": small2}, None, 3, average=True)
+    over = (tuple(probe["g"].shape), probe["g"][:, 0].tolist(), float(small2[0]), sorted(res), tuple(res["dL_drot"].shape))
+    q.put((r, w, arena[:4].tolist(), float(arena[-1]), views, {k: tuple(v.shape) for k, v in parts.items()}, fact, over))
     torch.distributed.destroy_process_group()
 
 
@@ -51,7 +59,8 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r, w, head, tail, views, shapes, fact in res:
+    for r, w, head, tail, views, shapes, fact, over in res:
+        assert over == ((2, 3004), [0.0, 10000.0], 1.5, ["dL_dmean3D", "dL_dopacity", "dL_drot", "dL_dscale", "dL_dshs"], (1000, 4))
         assert fact[0] == (2, 3004) and fact[1] == 1.5 and fact[2] == 1.5
         assert fact[3] == [0.0, 10000.0] and fact[4] == [3003.0, 13003.0]
         assert fact[5] == {"dL_dmean3D": (1000, 3), "dL_dscale": (1000, 3), "dL_drot": (1000, 4), "dL_dopacity": (1000,)}

@@ -79,3 +79,40 @@ def test_view_exchange_error_paths(scenes):
     assert out.shape == (160, 3) and not out.any()
     with pytest.raises(ValueError):
         gsr.backward(background=np.zeros(3, np.float32), means3D=means, dL_dpixels=torch.zeros((8, 8, 3), device="cuda"), sh_gradient="sparse")
+
+
+def test_overlapped_exchange_single_process(cameras, scenes):
+    """backward(..., on_payload=hook) takes the payload from the blend half (gsr_backward_blend) and skips the SH outputs of
+    the per-Gaussian half (gsr_backward_geom); FactoredExchange.finish then rebuilds dL_dshs.  Single process: V = 1."""
+    import torch
+    gsr = pkg()
+    scene = scenes.synthetic_scene(30000, 0.03, 0.6, seed=6)
+    scene["shs"][::2] *= 5.0
+    (cam, fkw, buf, dpix), = _views(gsr, scene, cameras, [5], 192, 3)
+    bkw = backward_kwargs(scene, cam, fkw, buf, dpix)
+    seen = []
+    ex = gsr.dist.FactoredExchange()
+
+    def hook(payload):
+        seen.append(payload)
+        ex.start_gather(payload)
+
+    g = gsr.backward(**bkw, sh_gradient="factored", on_payload=hook)
+    n = g["dL_dmean3D"].shape[0]
+    assert len(seen) == 1 and seen[0] is g["_view_payload"] and g["dL_dshs"] is None
+    pay = g["_view_payload"]
+    vis = (buf["radii"] > 0).unsqueeze(1)
+    expect = torch.where(vis, g["dL_dcolor"] * (1.0 + (-1.0 * buf["clamped_state"])), torch.zeros_like(g["dL_dcolor"]))
+    assert torch.equal(pay[: 3 * n].view(n, 3), expect)               # the early payload == what the geom half derives it from
+    np.testing.assert_array_equal(pay[3 * n: 3 * n + 3].cpu().numpy(), np.asarray(cam["camera_center"], np.float32))
+    means = torch.as_tensor(scene["means"]).cuda().contiguous()
+    res = ex.finish(g, means, 3, average=True)
+    assert set(res) == {"dL_dshs", "dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity"}
+    assert torch.equal(res["dL_dmean3D"], g["dL_dmean3D"])
+    dense = gsr.backward(**bkw, sh_gradient="both")                     # a second replay: equal up to float-atomic order
+    tol = dict(rtol=2e-3, atol=1e-4 * float(dense["dL_dshs"].abs().max()))
+    np.testing.assert_allclose(res["dL_dshs"].cpu().numpy(), dense["dL_dshs"].cpu().numpy(), **tol)
+    np.testing.assert_allclose(res["dL_dmean3D"].cpu().numpy(), dense["dL_dmean3D"].cpu().numpy(), rtol=2e-3,
+                               atol=1e-4 * float(dense["dL_dmean3D"].abs().max()))
+    # and exactly: rebuilt from THIS call's payload == the single-view kernel on the same payload
+    assert torch.equal(res["dL_dshs"], gsr.dist.sh_gradients_from_views(means, [pay], 3, average=False))

@@ -9,9 +9,10 @@ dist.init_process_group(backend="nccl", device_id=dev)
 a = torch.arange(11 * 1000, dtype=torch.float32, device=dev)
 p = torch.arange(3 * 1000 + 4, dtype=torch.float32, device=dev)
 g = torch.empty((1, p.numel()), device=dev)
-w = dist.all_gather_into_tensor(g.view(-1), p, async_op=True)
-dist.all_reduce(a, op=dist.ReduceOp.AVG)
+w = dist.all_gather_into_tensor(g.view(-1), p, async_op=True)          # FactoredExchange.start_gather
+r = dist.all_reduce(a, op=dist.ReduceOp.AVG, async_op=True)             # FactoredExchange.finish
 w.wait()
+r.wait()
 torch.cuda.synchronize()
 assert torch.equal(g[0], p) and float(a[5]) == 5.0
 dist.barrier()
