@@ -205,15 +205,30 @@ def main():
             geom = {"radii": ob["radii"], "means2D": ob["points_xy_image"], "conic_opacity": ob["conic_opacity"], "rgb": ob["colors"],
                     "clamped_state": ob["clamped_state"]}
             t0 = time.perf_counter()
-            oracle.backward(background=bg, means3D=sc["means"], dL_dpixels=dpix.cpu().numpy(), opacity=sc["opacities"], shs=sc["shs"],
+            og = oracle.backward(background=bg, means3D=sc["means"], dL_dpixels=dpix.cpu().numpy(), opacity=sc["opacities"], shs=sc["shs"],
                             scales=sc["scales"], rotations=sc["rotations"], viewmatrix=fkw["viewmatrix"], projmatrix=fkw["projmatrix"],
                             tan_fovx=fkw["tan_fovx"], tan_fovy=fkw["tan_fovy"], image_height=H, image_width=W, campos=fkw["campos"],
                             cov3Ds=ob["cov3Ds"], geom_buffer=geom, binning_buffer={"point_list": ob["point_list"]},
                             img_buffer={"ranges": ob["ranges"], "final_Ts": ob["final_Ts"], "n_contrib": ob["n_contrib"]})
             t_b = time.perf_counter() - t0
+            # the same frame is also a full-size parity check of the timed path (the oracle as checker, outside the timed region)
+            gb, gg = step()
+            torch.cuda.synchronize()
+            gi = gsr.render_gaussians(**fkw)[0].cpu().numpy()
+            ierr = np.abs(gi.astype(np.float64) - oi).max(axis=2)
+            par = {"image_max_abs_err": float(ierr.max()), "image_frac_within_2e-5": float((ierr <= 2e-5).mean()),
+                   "n_contrib_frac_equal": float((gb["n_contrib"].cpu().numpy() == ob["n_contrib"]).mean())}
+            for k in ("radii", "point_offsets", "point_list", "ranges"):
+                a, b = gb[k].cpu().numpy(), np.asarray(ob[k])
+                par[k + "_exact"] = bool(a.shape == b.shape and (a == b).all())
+            for k in ("dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dshs"):
+                a, b = gg[k].cpu().numpy().astype(np.float64), np.asarray(og[k], dtype=np.float64)
+                m = np.abs(b).max()
+                par[k + "_frac_within_tol"] = float((np.abs(a - b) <= 1e-4 * m + 2e-3 * np.abs(b)).mean())   # tests/parity.py
             out["cpu_baseline"] = {"value": round(W * H / (t_f + t_b) / 1e6, 5), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                                    "sample": f"one full {args.config} frame (same scene and view), forward {t_f:.2f} s + backward {t_b:.2f} s, "
-                                             f"single-thread C oracle (gcc -O2), host has {os.cpu_count()} cores"}
+                                             f"single-thread C oracle (gcc -O2), host has {os.cpu_count()} cores",
+                                   "parity_full_size": {k: (round(v, 8) if isinstance(v, float) else v) for k, v in par.items()}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

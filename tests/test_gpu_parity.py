@@ -101,6 +101,16 @@ def test_c2_lego_100k(oracle, cameras, scenes):
     print("C2 parity report:", report)
 
 
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_full_size_configs(oracle, cameras, scenes, name):
+    """BASELINE configs #3 (800x800, 1 M Gaussians: the headline workload) and #5 (1920x1080, 5 M Gaussians, 64-bit tile
+    items, large-n radix path) against the oracle at FULL size -- the single-thread C oracle needs about 4 s / 25 s for them."""
+    cfg = scenes.CONFIGS[name]
+    sc = scenes.synthetic_scene(cfg["n"], cfg["scale_median"], cfg["scale_sigma"], cfg["seed"])
+    cam = cameras.nerf_camera(scenes.LEGO_FRAME0, cfg["width"], cfg["height"], scenes.LEGO_CAMERA_ANGLE_X)
+    _fwd_bwd(oracle, sc, cam, cfg["width"], cfg["height"])
+
+
 def test_empty_and_culled(oracle, cameras, scenes):
     gsr = pkg()
     cam = lego_camera(cameras, frame=0, width=64, height=48)
