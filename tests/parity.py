@@ -6,16 +6,18 @@ Tolerances (stated here, used by every test):
   * float per-Gaussian outputs (xy, depth, cov3D, conic, colour) within 1e-6 relative: both sides
     evaluate the same float32 expression tree without FMA contraction, with correctly rounded
     division and sqrt, so they are expected to be bit-identical;
-  * image / inverse depth / final_T: |d| <= 2e-5 on >= 99.9 % of pixels and <= 2e-3 on the rest.
+  * image / inverse depth / final_T: |d| <= 2e-5 on >= 99.9 % of pixels and <= 5e-3 on the rest (one flipped
+    alpha < 1/255 test moves T by up to T/255 = 3.9e-3: seed 1752 of the round-1 sweep, 2.8e-3 at one pixel).
     The only arithmetic difference is exp(): v_exp_f32(x*log2e) on the GPU vs libm expf in the
     oracle (relative error < 5e-7); the "rest" are pixels where that flips one of the discrete tests
     alpha < 1/255 or T < 1e-4;
   * n_contrib exact on >= 99.9 % of pixels;
   * gradients: |d| <= 1e-4 * max|g| + 2e-3 * |g| element-wise on >= 99.9 % of the elements and
     <= 2e-2 * max|g| on the rest (float sums are re-associated: wave/tile reduction + atomics vs the
-    oracle's serial order); an array of fewer than 1000 elements may have ONE element in
-    the loose band (a 64-Gaussian case with a 30:1 anisotropic splat put one dL_dmean3D component at 1.1e-4 * max|g|
-    in one run of the round-1 sweep and at 0.65e-4 in the next: atomic order).
+    oracle's serial order); in an array of fewer than 4000 elements the components
+    of ONE Gaussian (up to 4) may sit in the loose band: one flipped alpha < 1/255 test in the replay, or float-atomic
+    order on an ill-conditioned splat, moves all components of that Gaussian's gradient (seeds 21 and 2673 of the round-1
+    sweeps: 1.1e-4 * max|g| in one run, 0.65e-4 in the next).
 """
 import numpy as np
 
@@ -41,7 +43,7 @@ def assert_close_rel(name, got, ref, rtol=1e-6, atol=1e-9):
     return float((got == ref).mean())
 
 
-def assert_image(name, got, ref, tight=2e-5, loose=2e-3, frac=0.999):
+def assert_image(name, got, ref, tight=2e-5, loose=5e-3, frac=0.999):
     got, ref = to_np(got), to_np(ref)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
     err = np.abs(got.astype(np.float64) - ref)
@@ -69,7 +71,7 @@ def assert_grad(name, got, ref, frac=0.999):
         return 1.0, 0.0
     err = np.abs(got - ref)
     ok = float((err <= 1e-4 * m + 2e-3 * np.abs(ref)).mean())
-    need = min(frac, 1.0 - 1.0 / ref.size)   # arrays under 1000 elements: one element may sit in the loose band too
+    need = min(frac, 1.0 - 4.0 / ref.size)   # small arrays: one Gaussian's components (<= 4) may sit in the loose band too
     assert ok >= need, f"{name}: only {ok:.5f} within tolerance (max err {err.max():.3e}, max|g| {m:.3e})"
     assert err.max() <= 2e-2 * m, f"{name}: max err {err.max():.3e} vs max|g| {m:.3e}"
     return ok, float(err.max() / m)
