@@ -37,6 +37,84 @@ __global__ __launch_bounds__(256) void l1_loss_grad_kernel(const float *__restri
     if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+// ---- loss.py:47-119 (ssim_kernel): one 16x16 pixel tile per workgroup, the tile and its 5-pixel halo of both images staged
+// in LDS (26 x 26 x 6 floats), each thread then walks its 11 x 11 window with the reference's accumulation order (row by
+// row, x fastest).  Window weights are indexed by DISTANCE into a Gaussian centred on index 5 (quirk Q21): w[d] as passed.
+struct SsimW { float w[6]; };
+__global__ __launch_bounds__(256) void ssim_kernel(const float *__restrict__ rendered, const float *__restrict__ target, float *__restrict__ ssim_sum,
+                                                   int W, int H, SsimW gw)
+{
+    constexpr int HALF = 5, SIDE = 16 + 2 * HALF;
+    __shared__ float s_r[SIDE * SIDE * 3], s_t[SIDE * SIDE * 3];
+    __shared__ float s_part[4];
+    const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
+    for (int k = threadIdx.x; k < SIDE * SIDE; k += 256) {
+        const int ly = k / SIDE, lx = k - ly * SIDE;
+        const int y = ty0 + ly - HALF, x = tx0 + lx - HALF;
+        const bool in = x >= 0 && x < W && y >= 0 && y < H;
+        const size_t g = in ? 3 * ((size_t)y * W + x) : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s_r[3 * k + c] = in ? rendered[g + c] : 0.0f;
+            s_t[3 * k + c] = in ? target[g + c] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int i = tx0 + lx, j = ty0 + ly;
+    float val = 0.0f;
+    if (i < W && j < H) {
+        float mu1[3] = {0.f, 0.f, 0.f}, mu2[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f}, s12[3] = {0.f, 0.f, 0.f};
+        float weight_sum = 0.0f;
+        const int y0 = max(0, j - HALF), y1 = min(H, j + HALF + 1), x0 = max(0, i - HALF), x1 = min(W, i + HALF + 1);
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const float w = gw.w[abs(x - i)] * gw.w[abs(y - j)];
+                const int k = 3 * ((y - ty0 + HALF) * SIDE + (x - tx0 + HALF));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float p1 = s_r[k + c], p2 = s_t[k + c];
+                    mu1[c] += p1 * w;
+                    mu2[c] += p2 * w;
+                    s1[c] += (p1 * p1) * w;
+                    s2[c] += (p2 * p2) * w;
+                    s12[c] += (p1 * p2) * w;
+                }
+                weight_sum += w;
+            }
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        float ss[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float m1 = mu1[c], m2 = mu2[c], a1 = s1[c], a2 = s2[c], a12 = s12[c];
+            if (weight_sum > 0.0f) { m1 /= weight_sum; m2 /= weight_sum; a1 /= weight_sum; a2 /= weight_sum; a12 /= weight_sum; }
+            const float v1 = a1 - m1 * m1, v2 = a2 - m2 * m2, v12 = a12 - m1 * m2;
+            ss[c] = ((2.0f * m1 * m2 + c1) * (2.0f * v12 + c2)) / ((m1 * m1 + m2 * m2 + c1) * (v1 + v2 + c2));
+        }
+        val = (ss[0] + ss[1] + ss[2]) / 3.0f;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = val;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(ssim_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// ---- loss.py:247-269 (depth_loss_kernel): sum |rendered - target| * mask ----
+__global__ __launch_bounds__(256) void depth_loss_kernel(const float *__restrict__ rendered, const float *__restrict__ target,
+                                                         const float *__restrict__ mask, float *__restrict__ loss_sum, int64_t n)
+{
+    __shared__ float s_part[4];
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += fabsf(rendered[i] - target[i]) * mask[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 // ---- f3: reference optimizer.py:7-139 (adam_update) ----
 struct AdamK {
     float beta1, beta2, omb1, omb2, eps, bc1, bc2;
@@ -142,6 +220,35 @@ int gsr_l1_loss_grad(const float *rendered, const float *target, float *pixel_gr
     const int64_t n = (int64_t)W * H * 3;
     const unsigned blocks = (unsigned)std::min<int64_t>(2048, gsr_div_up(gsr_div_up(n, 4), 256));
     hipLaunchKernelGGL(l1_loss_grad_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, rendered, target, pixel_grad, loss_sum, n, l1_weight);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
+}
+
+int gsr_ssim(const float *rendered, const float *target, float *ssim_sum, int32_t W, int32_t H, void *stream)
+{
+    if (!rendered || !target || !ssim_sum) return GSR_E_NULL;
+    if (W <= 0 || H <= 0) return GSR_E_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    SsimW gw; // loss.py:33-45 with sigma = 1.5, window 11: kernel[k] = exp(-(k-5)^2 / 4.5), used at k = distance (Q21)
+    const float sigma = 1.5f;
+    for (int k = 0; k < 6; ++k) {
+        const int x = k - 5;
+        gw.w[k] = expf(-1.0f * (float)(x * x) / (2.0f * sigma * sigma));
+    }
+    if (hipMemsetAsync(ssim_sum, 0, sizeof(float), s) != hipSuccess) return GSR_E_HIP;
+    hipLaunchKernelGGL(ssim_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, rendered, target, ssim_sum, W, H, gw);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
+}
+
+int gsr_depth_loss(const float *rendered_depth, const float *target_depth, const float *depth_mask, float *loss_sum, int32_t W, int32_t H,
+                   void *stream)
+{
+    if (!rendered_depth || !target_depth || !depth_mask || !loss_sum) return GSR_E_NULL;
+    if (W <= 0 || H <= 0) return GSR_E_DIMS;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)W * H;
+    if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return GSR_E_HIP;
+    hipLaunchKernelGGL(depth_loss_kernel, dim3((unsigned)std::min<int64_t>(1024, gsr_div_up(n, 256))), dim3(256), 0, s, rendered_depth, target_depth,
+                       depth_mask, loss_sum, n);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
 }
 

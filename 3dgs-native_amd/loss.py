@@ -37,3 +37,33 @@ def l1_loss(rendered, target):
 def compute_image_gradients(rendered, target, lambda_dssim=0.2):
     """dL/dpixels for backward() (reference loss.py:217-244)."""
     return l1_loss_and_gradients(rendered, target, lambda_dssim)[1]
+
+
+def ssim(rendered, target):
+    """Mean SSIM as a Python float (reference loss.py:178-215: 11x11 window, sigma 1.5, weights indexed by distance as the
+    reference does -- see gsr.h).  An evaluation helper: the reference's training loop has its SSIM term commented out."""
+    L = _lib.lib()
+    dev = _host.device_of(rendered, target)
+    r = _host.to_dev(rendered, torch.float32, dev)
+    H, W = int(r.shape[0]), int(r.shape[1])
+    r = r.reshape(H, W, 3)
+    t = _host.to_dev(target, torch.float32, dev, (H, W, 3))
+    acc = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.gsr_ssim(_host.ptr(r), _host.ptr(t), _host.ptr(acc), W, H, _host.stream_ptr(dev)))
+    return float(acc.item()) / (W * H)
+
+
+def depth_loss(rendered_depth, target_depth, depth_mask):
+    """Masked mean L1 between inverse-depth images as a Python float (reference loss.py:271-303)."""
+    L = _lib.lib()
+    dev = _host.device_of(rendered_depth, target_depth, depth_mask)
+    r = _host.to_dev(rendered_depth, torch.float32, dev)
+    H, W = int(r.shape[0]), int(r.shape[1])
+    r = r.reshape(H, W)
+    t = _host.to_dev(target_depth, torch.float32, dev, (H, W))
+    m = _host.to_dev(depth_mask, torch.float32, dev, (H, W))
+    acc = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.gsr_depth_loss(_host.ptr(r), _host.ptr(t), _host.ptr(m), _host.ptr(acc), W, H, _host.stream_ptr(dev)))
+    return float(acc.item()) / (W * H)

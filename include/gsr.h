@@ -180,6 +180,17 @@ int gsr_backward_geom(const GsrScene *scene, const GsrCamera *camera, const GsrG
 int gsr_l1_loss_grad(const float *rendered, const float *target, float *pixel_grad, float *loss_sum, int32_t W, int32_t H,
                      float l1_weight, void *stream);
 
+/* The other two entry points of the reference's loss.py (evaluation helpers; train.py:968-972 has the SSIM term commented
+ * out and calls compute_image_gradients with lambda_dssim = 0):
+ *   gsr_ssim        loss.py:178-215 (ssim -> gaussian_kernel :33-45 + ssim_kernel :47-119): *ssim_sum = sum over pixels of the
+ *                   channel-averaged SSIM in an 11x11 window; the caller divides by W*H.  Window weights as the reference
+ *                   applies them: indexed by distance into a Gaussian centred on index 5 (so the rim weighs most).
+ *   gsr_depth_loss  loss.py:271-303 (depth_loss -> depth_loss_kernel :247-269): *loss_sum = sum |rendered - target| * mask
+ *                   over [H*W] inverse-depth images; the caller divides by W*H. */
+int gsr_ssim(const float *rendered, const float *target, float *ssim_sum /* device, overwritten */, int32_t W, int32_t H, void *stream);
+int gsr_depth_loss(const float *rendered_depth, const float *target_depth, const float *depth_mask, float *loss_sum /* device, overwritten */,
+                   int32_t W, int32_t H, void *stream);
+
 /* f3  Fused Adam step with the reference's clamps (reference optimizer.py:7-139, launched at train.py:750-794):
  *     scale >= 1e-3, quaternion renormalised, opacity clamped to [0,1], +1e-9 in the vec3 divisions
  *     (utils/wp_utils.py:15-20).  grad pointers may be the slices of the backward's gradient arena. */

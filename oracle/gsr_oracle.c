@@ -635,6 +635,68 @@ float gsro_l1_loss_sum(int W, int H, const float *rendered, const float *target)
     return acc;
 }
 
+/* loss.py:33-45 (gaussian_kernel) + :47-119 (ssim_kernel) + :178-215 (ssim).  Quirk Q21: the 11 window weights are
+ * kernel[k] = exp(-(k-5)^2 / (2 sigma^2)) -- a Gaussian centred on INDEX 5 -- but the kernel indexes them by DISTANCE
+ * (gaussian_weights[|x-i|], loss.py:81-84), so a tap at distance d weighs exp(-(d-5)^2/4.5): largest at the rim of the
+ * window, smallest at the centre.  Reproduced as written.  Launch dim=(width,height): i = x outer, j = y fastest (A7).
+ * Returns the raw sum of per-pixel SSIM values; the caller divides by W*H (loss.py:214). */
+float gsro_ssim_sum(int W, int H, const float *rendered, const float *target)
+{
+    const int window_size = 11, half_window = window_size / 2;
+    const float sigma = 1.5f;
+    float gw[11];
+    for (int i = 0; i < window_size; ++i) {
+        const int x = i - window_size / 2;
+        gw[i] = expf(-1.0f * (float)(x * x) / (2.0f * sigma * sigma));
+    }
+    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+    float total = 0.0f;
+    for (int i = 0; i < W; ++i)
+        for (int j = 0; j < H; ++j) {
+            float mu1[3] = {0, 0, 0}, mu2[3] = {0, 0, 0}, s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, s12[3] = {0, 0, 0}, weight_sum = 0.0f;
+            const int y0 = j - half_window > 0 ? j - half_window : 0, y1 = j + half_window + 1 < H ? j + half_window + 1 : H;
+            const int x0 = i - half_window > 0 ? i - half_window : 0, x1 = i + half_window + 1 < W ? i + half_window + 1 : W;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const int wy = abs(y - j), wx = abs(x - i);
+                    if (wx <= half_window && wy <= half_window) {
+                        const float w = gw[wx] * gw[wy];
+                        const float *p1 = rendered + 3 * ((size_t)y * W + x), *p2 = target + 3 * ((size_t)y * W + x);
+                        for (int c = 0; c < 3; ++c) {
+                            mu1[c] += p1[c] * w;
+                            mu2[c] += p2[c] * w;
+                            s1[c] += (p1[c] * p1[c]) * w;
+                            s2[c] += (p2[c] * p2[c]) * w;
+                            s12[c] += (p1[c] * p2[c]) * w;
+                        }
+                        weight_sum += w;
+                    }
+                }
+            if (weight_sum > 0.0f)
+                for (int c = 0; c < 3; ++c) { mu1[c] /= weight_sum; mu2[c] /= weight_sum; s1[c] /= weight_sum; s2[c] /= weight_sum; s12[c] /= weight_sum; }
+            float ss[3];
+            for (int c = 0; c < 3; ++c) {
+                const float v1 = s1[c] - mu1[c] * mu1[c], v2 = s2[c] - mu2[c] * mu2[c], v12 = s12[c] - mu1[c] * mu2[c];
+                ss[c] = ((2.0f * mu1[c] * mu2[c] + c1) * (2.0f * v12 + c2)) / ((mu1[c] * mu1[c] + mu2[c] * mu2[c] + c1) * (v1 + v2 + c2));
+            }
+            total += (ss[0] + ss[1] + ss[2]) / 3.0f;
+        }
+    return total;
+}
+
+/* loss.py:247-269 (depth_loss_kernel) + :271-303 (depth_loss): sum |rendered - target| * mask, x outer / y fastest; the
+ * caller divides by W*H (loss.py:302). */
+float gsro_depth_loss_sum(int W, int H, const float *rendered, const float *target, const float *mask)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < W; ++i)
+        for (int j = 0; j < H; ++j) {
+            const size_t k = (size_t)j * W + i;
+            acc += fabsf(rendered[k] - target[k]) * mask[k];
+        }
+    return acc;
+}
+
 /* loss.py:122-146 (backprop_l1_pixel_gradients); wp.sign(x) = -1 if x < 0 else +1 (assumption A9). */
 void gsro_l1_pixel_grad(int W, int H, const float *rendered, const float *target, float l1_weight, float *pixel_grad)
 {

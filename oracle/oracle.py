@@ -41,6 +41,8 @@ def lib():
                      "gsro_cov3d_backward", "gsro_l1_pixel_grad", "gsro_adam_update"):
             getattr(_LIB, name).restype = None
         _LIB.gsro_l1_loss_sum.restype = C.c_float
+        _LIB.gsro_ssim_sum.restype = C.c_float
+        _LIB.gsro_depth_loss_sum.restype = C.c_float
     return _LIB
 
 
@@ -213,6 +215,20 @@ def l1_loss(rendered, target):
     H, W = r.shape[0], r.shape[1]
     s = lib().gsro_l1_loss_sum(C.c_int(W), C.c_int(H), _f(r), _f(t))
     return float(s) / (W * H * 3)
+
+
+def ssim(rendered, target):
+    """Restates loss.py:178-215 (window weights indexed by distance, quirk Q21): serial float32 sum / (W*H)."""
+    r, t = _f32(rendered), _f32(target)
+    H, W = r.shape[0], r.shape[1]
+    return float(lib().gsro_ssim_sum(C.c_int(W), C.c_int(H), _f(r), _f(t))) / (W * H)
+
+
+def depth_loss(rendered_depth, target_depth, depth_mask):
+    """Restates loss.py:271-303."""
+    r, t, m = _f32(rendered_depth), _f32(target_depth), _f32(depth_mask)
+    H, W = r.shape[0], r.shape[1]
+    return float(lib().gsro_depth_loss_sum(C.c_int(W), C.c_int(H), _f(r), _f(t), _f(m))) / (W * H)
 
 
 def compute_image_gradients(rendered, target, lambda_dssim=0.2):

@@ -118,3 +118,19 @@ def test_l1_and_adam_size_sweep(oracle):
             np.testing.assert_allclose(dP[k].cpu().numpy(), P[k], rtol=2e-6, atol=1e-7, err_msg=f"param {k} n={n}")
             np.testing.assert_allclose(dM[k].cpu().numpy(), M[k], rtol=2e-6, atol=1e-9, err_msg=f"m {k} n={n}")
             np.testing.assert_allclose(dV[k].cpu().numpy(), V[k], rtol=2e-6, atol=1e-12, err_msg=f"v {k} n={n}")
+
+
+def test_ssim_and_depth_loss_match_oracle(oracle):
+    import torch
+    gsr = pkg()
+    rng = np.random.default_rng(31)
+    for (H, W) in [(1, 1), (5, 9), (16, 16), (17, 33), (64, 48), (200, 300)]:
+        a = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+        b = np.clip(a + rng.normal(0, 0.1, (H, W, 3)), 0, 1).astype(np.float32)
+        ref = oracle.ssim(a, b)
+        assert abs(gsr.loss.ssim(a, torch.as_tensor(b).cuda()) - ref) <= 2e-5 * max(1.0, abs(ref))   # per-pixel values identical, sum order differs
+        assert abs(gsr.loss.ssim(a, a) - 1.0) < 1e-5
+        d1, d2 = a[..., 0].copy(), b[..., 1].copy()
+        m = (rng.uniform(0, 1, (H, W)) > 0.3).astype(np.float32)
+        refd = oracle.depth_loss(d1, d2, m)
+        assert abs(gsr.loss.depth_loss(torch.as_tensor(d1).cuda(), d2, m) - refd) <= 2e-5 * max(1e-3, refd)

@@ -116,3 +116,21 @@ def test_zero_rendered_gives_zero_image(oracle, cameras, scenes):
     sc["means"] = (sc["means"] * 0.01 + np.asarray(cam["camera_center"], np.float32) * 3.0).astype(np.float32)
     img, dep, buf = oracle.render_gaussians(**render_kwargs(sc, cam, width=W, height=H, bg=(1, 1, 1)))
     assert buf["point_list"].shape == (0,) and img.max() == 0.0 and buf["final_Ts"].max() == 0.0   # quirk Q10
+
+
+def test_ssim_and_depth_loss_oracle_properties(oracle):
+    """loss.py's two evaluation helpers (restated with the reference's window-weight quirk Q21): identities and bounds."""
+    rng = np.random.default_rng(12)
+    a = rng.uniform(0, 1, (23, 31, 3)).astype(np.float32)
+    b = rng.uniform(0, 1, (23, 31, 3)).astype(np.float32)
+    assert abs(oracle.ssim(a, a) - 1.0) < 1e-6
+    assert abs(oracle.ssim(a, b) - oracle.ssim(b, a)) < 1e-7           # symmetric
+    assert oracle.ssim(a, b) < 0.2 < 0.99 < oracle.ssim(a, np.clip(a + 0.01, 0, 1).astype(np.float32))
+    const = np.full((9, 9, 3), 0.5, np.float32)
+    assert abs(oracle.ssim(const, const) - 1.0) < 1e-6                  # zero variance: c2/c2
+    d1, d2 = a[..., 0], b[..., 0]
+    ones = np.ones_like(d1)
+    assert abs(oracle.depth_loss(d1, d2, ones) - float(np.abs(d1 - d2).mean())) < 1e-6
+    assert oracle.depth_loss(d1, d2, np.zeros_like(d1)) == 0.0
+    half = ones.copy(); half[:, 16:] = 0
+    assert abs(oracle.depth_loss(d1, d2, half) - float((np.abs(d1 - d2) * half).mean())) < 1e-6
