@@ -86,6 +86,7 @@ EXPORTS = {
     "gsr_clone_gaussians": (C.c_int, [C.POINTER(GsrParams), vp, vp, C.c_float, C.POINTER(GsrParams), vp]),
     "gsr_split_gaussians": (C.c_int, [C.POINTER(GsrParams), vp, vp, C.c_int32, C.c_float, C.POINTER(GsrParams), vp]),
     "gsr_compact_gaussians": (C.c_int, [C.POINTER(GsrParams), vp, vp, C.POINTER(GsrParams), vp]),
+    "gsr_init_gaussians": (C.c_int, [C.POINTER(GsrParams), C.c_float, vp]),
     "gsr_reset_opacities": (C.c_int, [C.c_int64, C.c_float, vp, vp]),
     "gsr_stage_timing": (C.c_int, [C.c_int, C.c_int]),
     "gsr_stage_sampling": (C.c_int, [C.c_int]),

@@ -144,6 +144,31 @@ __global__ __launch_bounds__(256) void compact_kernel(GsrParams in, const int32_
     move_part(in, i, out, dst, (int)(t & 15), e);
 }
 
+// init_gaussian_params (train.py:37-92): positions = randf(3i+k) * 2.6 - 1.3, scales = init_scale, rotation = (1, 0, 0, 0) as
+// stored (x, y, z, w -- not the identity of that convention; kept), opacity 0.1, SH DC = -0.007, higher bands 0.
+// 16 lanes per Gaussian like the movers, so the SH row is written as whole 64-byte segments.
+__global__ __launch_bounds__(256) void init_kernel(GsrParams out, float init_scale)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t >> 4;
+    const int part = (int)(t & 15);
+    if (i >= out.N) return;
+    if (part < 12) {
+        reinterpret_cast<float4 *>(out.shs)[i * 12 + part] = part == 0 ? make_float4(-0.007f, -0.007f, -0.007f, 0.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (part == 12) {
+        const int32_t i3 = (int32_t)i * 3;
+        out.positions[i * 3 + 0] = randf((uint32_t)i3) * 2.6f - 1.3f;
+        out.positions[i * 3 + 1] = randf((uint32_t)(i3 + 1)) * 2.6f - 1.3f;
+        out.positions[i * 3 + 2] = randf((uint32_t)(i3 + 2)) * 2.6f - 1.3f;
+    } else if (part == 13) {
+        out.scales[i * 3 + 0] = init_scale; out.scales[i * 3 + 1] = init_scale; out.scales[i * 3 + 2] = init_scale;
+    } else if (part == 14) {
+        reinterpret_cast<float4 *>(out.rotations)[i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        out.opacities[i] = 0.1f;
+    }
+}
+
 // reset_opacities (optimizer.py:141-156)
 __global__ __launch_bounds__(256) void fill_kernel(int64_t N, float v, float *__restrict__ p)
 {
@@ -238,6 +263,15 @@ int gsr_compact_gaussians(const GsrParams *in, const int32_t *valid, const int32
     if (in->N == 0 || out->N == 0) return GSR_OK;
     if (!valid || !prefix) return GSR_E_NULL;
     hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(in->N * 16)), dim3(256), 0, (hipStream_t)stream, *in, valid, prefix, *out);
+    return done();
+}
+
+int gsr_init_gaussians(const GsrParams *out, float init_scale, void *stream)
+{
+    if (!params_ok(out)) return GSR_E_NULL;
+    if (out->N < 0 || out->N > MAX_ROWS) return GSR_E_DIMS;
+    if (out->N == 0) return GSR_OK;
+    hipLaunchKernelGGL(init_kernel, dim3(blocks_for(out->N * 16)), dim3(256), 0, (hipStream_t)stream, *out, init_scale);
     return done();
 }
 

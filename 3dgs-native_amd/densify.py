@@ -143,6 +143,19 @@ def reset_opacities(opacities, max_opacity=0.01):
         _lib.check(_lib.lib().gsr_reset_opacities(int(opacities.numel()), float(max_opacity), _host.ptr(opacities), _host.stream_ptr(dev)))
 
 
+def init_gaussian_params(num_points, init_scale=0.1, device="cuda"):
+    """The trainer's initial point set (train.py:37-92, 193-214): seeded by the row index alone, so every rank and every run
+    starts from the same Gaussians."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    out = alloc_params(int(num_points), dev)
+    p = _params_struct(out, int(num_points))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().gsr_init_gaussians(C.byref(p), float(init_scale), _host.stream_ptr(dev)))
+    return out
+
+
 def calculate_scene_extent(camera_centers, camera_extent_factor=1.0):
     """Radius of the camera positions around their centroid, at least 1 (train.py:233-257)."""
     c = np.asarray(camera_centers)

@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--densify-interval", type=int, default=100)
     ap.add_argument("--opacity-reset-interval", type=int, default=3000)
     ap.add_argument("--save-interval", type=int, default=500)   # config.py:32
+    ap.add_argument("--init", default="reference", choices=["reference", "random"], help="initial Gaussians: the reference's "
+                    "init_gaussian_params, or a seeded random scene")
     ap.add_argument("--backend", default=None, help="collective backend (default: nccl = RCCL); gloo + --single-device rehearses N ranks on one GPU")
     ap.add_argument("--single-device", action="store_true")
     ap.add_argument("--output", default=None, help="directory for point_cloud/iteration_N/point_cloud.ply")
@@ -81,11 +83,15 @@ def main():
                                              sh=hidden["shs"], degree=3, campos=c["camera_center"])
             targets.append(img)
 
-    init = gsr.scenes.synthetic_scene(args.gaussians, 0.05, 0.5, seed=8)    # same on every rank (replicated parameters)
-    t = lambda a, shape: torch.as_tensor(np.ascontiguousarray(a, np.float32)).reshape(shape).to(dev)
     n = args.gaussians
-    P = {"positions": t(init["means"], (n, 3)), "scales": t(init["scales"], (n, 3)), "rotations": t(init["rotations"], (n, 4)),
-         "opacities": t(init["opacities"], (n,)), "shs": t(init["shs"], (n * 16, 3))}
+    if args.init == "reference":
+        # the reference trainer's start (train.py:37-92, 193-214): randf-hashed positions in (-1.3, 1.3)^3, scale 0.1, opacity 0.1
+        P = gsr.densify.init_gaussian_params(n, 0.1, dev)
+    else:
+        init = gsr.scenes.synthetic_scene(n, 0.05, 0.5, seed=8)             # same on every rank (replicated parameters)
+        t = lambda a, shape: torch.as_tensor(np.ascontiguousarray(a, np.float32)).reshape(shape).to(dev)
+        P = {"positions": t(init["means"], (n, 3)), "scales": t(init["scales"], (n, 3)), "rotations": t(init["rotations"], (n, 4)),
+             "opacities": t(init["opacities"], (n,)), "shs": t(init["shs"], (n * 16, 3))}
     model = gsr.densify.GaussianModel(
         P, scene_extent=gsr.densify.calculate_scene_extent([c["camera_center"] for c in cams]),
         config={"densify_from_iter": args.densify_from, "densify_until_iter": args.densify_until, "densification_interval": args.densify_interval,

@@ -265,6 +265,9 @@ int gsr_split_gaussians(const GsrParams *in, const int32_t *mask, const int32_t 
 /* out row prefix[i] = in row i where valid[i] != 0; rows at or past out->N are dropped */
 int gsr_compact_gaussians(const GsrParams *in, const int32_t *valid, const int32_t *prefix, const GsrParams *out, void *stream);
 int gsr_reset_opacities(int64_t N, float max_opacity, float *opacities, void *stream);
+/* init_gaussian_params (train.py:37-92, launched at train.py:193-214): positions randf(3i+k)*2.6-1.3, scales init_scale,
+ * rotations (1,0,0,0) as stored, opacities 0.1, SH DC -0.007 and zeros above. */
+int gsr_init_gaussians(const GsrParams *out, float init_scale, void *stream);
 
 /* ---- profiling aid (the only process-wide state in the library; not thread-safe) ----------------
  * With timing enabled every stage boundary of the three entry points records a hipEvent on the

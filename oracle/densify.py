@@ -142,6 +142,19 @@ def compact_gaussians(params, valid, prefix, count):
     return out
 
 
+def init_gaussian_params(num_points, init_scale=0.1):
+    """train.py:37-92"""
+    n = int(num_points)
+    out = alloc(n)
+    i3 = (np.arange(n, dtype=np.int64) * 3).astype(np.int32)
+    out["positions"] = np.stack([randf(i3) * F(2.6) - F(1.3), randf(i3 + 1) * F(2.6) - F(1.3), randf(i3 + 2) * F(2.6) - F(1.3)], axis=1).astype(F)
+    out["scales"][:] = F(init_scale)
+    out["rotations"][:, 0] = F(1.0)
+    out["opacities"][:] = F(0.1)
+    out["shs"][:, :3] = F(-0.007)
+    return out
+
+
 # ---- the trainer sequence -------------------------------------------------------------------------------------------
 def densification_and_pruning(params, pos_grad, iteration, config, scene_extent):
     """train.py:351-713 on host arrays.  Returns (params, log); Adam state / gradients are the caller's to zero."""

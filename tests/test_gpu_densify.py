@@ -189,3 +189,14 @@ def test_trainer_sequence_sweep():
         ref, ref_log = od.densification_and_pruning(p, g, it, dict({"background_color": [0.0, 0.0, 0.0]}, **cfg), model.scene_extent)
         assert log == ref_log, (case, n, cfg, log, ref_log)
         assert_params_equal(model.params, ref)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5000, 100003])
+def test_init_gaussian_params_matches_oracle(n):
+    dz = sub("densify")
+    got = dz.init_gaussian_params(n, 0.1)
+    ref = od.init_gaussian_params(n, 0.1)
+    assert_params_equal(got, ref)
+    if n >= 5000:
+        p = got["positions"]
+        assert float(p.min()) >= -1.3 and float(p.max()) < 1.3 and abs(float(p.mean())) < 0.05   # train.py:52-56: U(-1.3, 1.3)
