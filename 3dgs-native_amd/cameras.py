@@ -7,11 +7,16 @@ reference's inputs bit-for-meaning:
 
 * `nerf_camera`  -- NeRF-synthetic `transform_matrix` -> the dict train.py feeds to the rasterizer
                     (reference utils/camera_utils.py:8-89; utils/math_utils.py:8-41).
+* `load_camera` / `load_camera_from_json` / `world_to_view` / `projection_matrix` / `matrix_to_quaternion`
+                 -- the reference's own helper names (utils/camera_utils.py:8-106, utils/math_utils.py:8-95) over the
+                    same math, for callers written against them.
 * `toy_camera`   -- the hard-coded camera of the 3-Gaussian demo (reference render.py:11-50), including
                     its quirk of passing the un-transposed `world_to_view` matrix as the view matrix
                      and degrees-as-radians FoV (tan(22.5 rad)).
 """
+import json
 import math
+import os
 
 import numpy as np
 
@@ -85,3 +90,85 @@ def toy_camera(image_width=1800, image_height=1800, fovx=45.0, fovy=45.0, znear=
         "width": image_width, "height": image_height,
         "focal_x": image_width / (2 * tan_fovx), "focal_y": image_height / (2 * tan_fovy),
     }
+
+
+# ---- the reference's helper names ------------------------------------------------------------------------------------
+def world_to_view(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
+    """World-to-view matrix [[R^T, t], [0, 1]] with the camera centre moved by `translate` and scaled by `scale`
+    (reference utils/math_utils.py:8-19), float32."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = np.asarray(R).T
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    c2w = np.linalg.inv(Rt)
+    c2w[:3, 3] = (c2w[:3, 3] + np.asarray(translate)) * scale
+    return np.float32(np.linalg.inv(c2w))
+
+
+def projection_matrix(fovx, fovy, znear, zfar):
+    """Perspective matrix, z_sign = +1, float64 (reference utils/math_utils.py:21-41)."""
+    return _projection(fovx, fovy, znear, zfar)
+
+
+def matrix_to_quaternion(matrix):
+    """3x3 rotation matrix -> quaternion (x, y, z, w) float32, largest-pivot form (reference utils/math_utils.py:43-95)."""
+    m = np.asarray(matrix, dtype=np.float64)
+    if abs(np.linalg.det(m) - 1.0) > 1e-5:
+        print(f"Warning: Input matrix determinant is not 1: {np.linalg.det(m)}")
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s4 = 2.0 * np.sqrt(tr + 1.0)                         # 4w
+        q = [(m[2, 1] - m[1, 2]) / s4, (m[0, 2] - m[2, 0]) / s4, (m[1, 0] - m[0, 1]) / s4, 0.25 * s4]
+    else:
+        a = 0 if (m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]) else (1 if m[1, 1] > m[2, 2] else 2)   # largest diagonal entry
+        b, c = (a + 1) % 3, (a + 2) % 3
+        s4 = 2.0 * np.sqrt(1.0 + m[a, a] - m[b, b] - m[c, c])  # 4 * q[a]
+        q = [0.0, 0.0, 0.0, (m[c, b] - m[b, c]) / s4]
+        q[a] = 0.25 * s4
+        q[b] = (m[a, b] + m[b, a]) / s4
+        q[c] = (m[a, c] + m[c, a]) / s4
+    return np.array(q, dtype=np.float32)
+
+
+_DISTORTION_KEYS = ("k1", "k2", "p1", "p2", "k3", "k4")
+_CAMERA_TYPES = {"OPENCV": 0, None: 0, "OPENCV_FISHEYE": 1}
+
+
+def load_camera(camera_info):
+    """Camera dict from a `camera_info` record -- `camera_id`, `camera_to_world` (OpenGL/Blender axes), `width`, `height`,
+    `focal`, optional `camera_model` and distortion coefficients -- with the 18 keys of reference
+    utils/camera_utils.py:8-89."""
+    _ = camera_info["camera_id"]
+    width, height, focal = camera_info.get("width"), camera_info.get("height"), camera_info.get("focal")
+    model = camera_info.get("camera_model", "OPENCV")
+    if model not in _CAMERA_TYPES:
+        raise ValueError(f"Unsupported camera_model '{model}'")
+    # pose-dependent entries (R, T, world_to_camera, view_matrix, camera_center) come from the same code as nerf_camera; the
+    # record carries the focal length itself, so everything that depends on it is formed from `focal` directly
+    cam = nerf_camera(camera_info["camera_to_world"], width, height, 2.0 * math.atan(width / (2.0 * focal)))
+    fovx, fovy = 2 * np.arctan(width / (2 * focal)), 2 * np.arctan(height / (2 * focal))
+    proj = _projection(fovx, fovy, 0.01, 100.0).T
+    c2w = np.asarray(camera_info["camera_to_world"], dtype=np.float64).copy()
+    c2w[:3, 1:3] *= -1
+    cam.update({"proj_matrix": proj, "full_proj_matrix": cam["world_to_camera"] @ proj, "tan_fovx": np.tan(fovx * 0.5),
+                "tan_fovy": np.tan(fovy * 0.5), "fx": focal, "fy": focal, "cx": width / 2, "cy": height / 2, "camera_to_world": c2w,
+                "camera_type": _CAMERA_TYPES[model],
+                "distortion_params": np.array([camera_info.get(k, 0.0) for k in _DISTORTION_KEYS], dtype=np.float32)})
+    return cam
+
+
+def load_camera_from_json(input_path, camera_id=0):
+    """`cameras.json` next to `input_path` -> load_camera of the record with that id, else of the first record; None when
+    the file is missing or unreadable (reference utils/camera_utils.py:93-113)."""
+    camera_file = os.path.join(os.path.dirname(input_path), "cameras.json")
+    if not os.path.exists(camera_file):
+        print(f"Warning: No cameras.json found in {os.path.dirname(input_path)}, using default camera")
+        return None
+    try:
+        with open(camera_file, "r") as f:
+            records = json.load(f)
+        chosen = next((c for c in records if c["id"] == camera_id), records[0])
+        return load_camera(chosen)
+    except Exception as e:   # noqa: BLE001 -- the reference swallows every error here and falls back to its default camera
+        print(f"Error loading camera from cameras.json: {e}")
+        return None

@@ -152,3 +152,42 @@ def test_header_is_plain_c_and_client_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)])
     subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "tests", "c_abi")])
     assert os.path.exists(os.path.join(ROOT, "tests", "c_abi", "gsr_client"))
+
+
+def test_reference_camera_helper_names(cameras):
+    """load_camera / world_to_view / projection_matrix / matrix_to_quaternion (reference utils/camera_utils.py, math_utils.py)."""
+    import json
+    from scipy.spatial.transform import Rotation
+    with open(os.path.join(ROOT, "tests", "golden", "lego_train_poses.json")) as f:
+        d = json.load(f)
+    W = H = 800
+    focal = 0.5 * W / np.tan(0.5 * d["camera_angle_x"])                     # train.py:296
+    info = {"camera_id": 3, "camera_to_world": d["frames"][3]["transform_matrix"], "width": W, "height": H, "focal": focal}
+    cam = cameras.load_camera(info)
+    ref = cameras.nerf_camera(d["frames"][3]["transform_matrix"], W, H, d["camera_angle_x"])
+    assert set(cam) == {"R", "T", "camera_center", "view_matrix", "proj_matrix", "full_proj_matrix", "tan_fovx", "tan_fovy", "fx", "fy", "cx",
+                        "cy", "width", "height", "camera_to_world", "world_to_camera", "camera_type", "distortion_params"}
+    for k in ("R", "T", "world_to_camera", "view_matrix", "camera_center"):
+        np.testing.assert_array_equal(cam[k], ref[k])
+    np.testing.assert_allclose(cam["full_proj_matrix"], ref["full_proj_matrix"], rtol=1e-12)
+    assert cam["camera_type"] == 0 and cam["distortion_params"].shape == (6,) and cam["cx"] == 400
+    assert cameras.load_camera(dict(info, camera_model="OPENCV_FISHEYE", k1=0.1))["distortion_params"][0] == np.float32(0.1)
+    with pytest.raises(ValueError):
+        cameras.load_camera(dict(info, camera_model="PINHOLE_X"))
+    assert cameras.load_camera_from_json("/nonexistent/dir/input.ply") is None
+    # world_to_view: translate / scale act on the camera centre
+    R, T = cam["R"], cam["T"]
+    v0 = cameras.world_to_view(R, T)
+    np.testing.assert_array_equal(v0, cam["view_matrix"])
+    v1 = cameras.world_to_view(R, T, translate=np.array([1.0, 2.0, 3.0]), scale=2.0)
+    c0, c1 = np.linalg.inv(v0)[:3, 3], np.linalg.inv(v1)[:3, 3]
+    np.testing.assert_allclose(c1, (c0 + [1.0, 2.0, 3.0]) * 2.0, rtol=1e-5)
+    P = cameras.projection_matrix(0.7, 0.5, 0.01, 100.0)
+    assert P[3, 2] == 1.0 and abs(P[0, 0] - 1.0 / np.tan(0.35)) < 1e-12 and abs(P[2, 2] - 100.0 / 99.99) < 1e-12
+    # matrix_to_quaternion: (x, y, z, w), every branch (trace > 0 and each largest-diagonal case), against scipy up to sign
+    rots = [Rotation.from_euler("xyz", e).as_matrix() for e in ([0.1, 0.2, 0.3], [3.0, 0.1, 0.1], [0.1, 3.0, 0.1], [0.1, 0.1, 3.0])]
+    rots += list(Rotation.random(20, random_state=5).as_matrix())
+    for m in rots:
+        q = cameras.matrix_to_quaternion(m)
+        r = Rotation.from_matrix(m).as_quat()
+        assert q.dtype == np.float32 and min(np.abs(q - r).max(), np.abs(q + r).max()) < 1e-6
