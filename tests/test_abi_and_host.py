@@ -191,3 +191,16 @@ def test_reference_camera_helper_names(cameras):
         q = cameras.matrix_to_quaternion(m)
         r = Rotation.from_matrix(m).as_quat()
         assert q.dtype == np.float32 and min(np.abs(q - r).max(), np.abs(q + r).max()) < 1e-6
+
+
+def test_gaussian_params_config_surface():
+    cfg = sub("config")
+    d = cfg.GaussianParams.get_config_dict()
+    assert d["num_points"] == 5000 and d["densify_grad_threshold"] == 0.0002 and d["lr_scheduler_config"]["lr_sh"] == 2e-3 and len(d) == 25
+    cfg.GaussianParams.update(num_points=123)
+    try:
+        assert cfg.GaussianParams.get_config_dict()["num_points"] == 123 and cfg.GaussianParams.num_points == 123
+        with pytest.raises(ValueError):
+            cfg.GaussianParams.update(not_a_parameter=1)
+    finally:
+        cfg.GaussianParams.update(num_points=5000)
