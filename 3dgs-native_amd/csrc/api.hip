@@ -219,8 +219,9 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, s));
     mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
-    // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id
-    // order, four 8-bit passes over the high word; ends back in depth_item) and the depth-order offsets.
+    // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id order, four 8-bit
+    // passes over the high word, ending back in depth_item; the last one also carries each Gaussian's tile rectangle and
+    // tile count to its sorted position) and the depth-order offsets (exclusive scan of those counts).
     {
         uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
         for (int pass = 0; pass < 3; ++pass) {

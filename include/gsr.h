@@ -277,9 +277,9 @@ int gsr_init_gaussians(const GsrParams *out, float init_scale, void *stream);
  * stage over the steps recorded since enabling, and clears the record. */
 enum {
     GSR_ST_PREPROCESS = 0, /* preprocess_kernel */
-    GSR_ST_SCAN,           /* id-order scan of tiles_touched (3 kernels) + async D readback */
-    GSR_ST_DEPTH_SORT,     /* 4 radix passes over N items (overlaps the host's wait for D) */
-    GSR_ST_DEPTH_SCAN,     /* depth-order offsets */
+    GSR_ST_SCAN,           /* id-order scan of tiles_touched (2 kernels); its last wave stores D to a pinned host word */
+    GSR_ST_DEPTH_SORT,     /* 4 radix passes over N items, the last one carrying rectangles + counts (overlaps the host wait for D) */
+    GSR_ST_DEPTH_SCAN,     /* depth-order offsets: exclusive scan of the carried counts */
     GSR_ST_HOST_GAP,       /* stream idle between gsr_forward_count and gsr_forward_render (host round trip) */
     GSR_ST_EXPAND,         /* (tile,id) item expansion */
     GSR_ST_TILE_SORT,      /* radix passes over D items */
