@@ -53,8 +53,9 @@ _ws = {}
 
 
 def workspace(kind, nbytes, dev):
-    """Grow-only scratch buffer per (kind, device)."""
-    key = (kind, dev.index)
+    """Grow-only scratch buffer per (kind, device, stream): calls issued on different streams (several views in flight on
+    one GPU) never share scratch."""
+    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
@@ -79,7 +80,8 @@ def records_ptr(tag, n, dev):
     if tag is None:
         return C.c_void_p(0)
     ws_tensor, gen, tn = tag
-    if tn != n or ws_tensor.device != dev or _ws_generation.get(id(ws_tensor), 0) != gen or _ws.get(("geom", dev.index)) is not ws_tensor:
+    if (tn != n or ws_tensor.device != dev or _ws_generation.get(id(ws_tensor), 0) != gen
+            or _ws.get(("geom", dev.index, torch.cuda.current_stream(dev).cuda_stream)) is not ws_tensor):
         return C.c_void_p(0)
     return C.c_void_p(ws_tensor.data_ptr())
 
