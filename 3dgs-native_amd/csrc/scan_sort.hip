@@ -252,22 +252,25 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const int64_t k = wave_base + r * 64 + lane;
         const bool valid = k < n;
         const int d = (int)((item[r] >> shift) & (RADIX - 1));
-        unsigned long long peers = __ballot(valid);
+        // lanes holding the same digit ("match any"): a lane differs from me in bit b where ballot(bit b) XOR (my bit b
+        // replicated) is set; OR over the bits, complement.  Written on 32-bit halves with the replicated bit as one signed
+        // bit-field extract, so a digit bit costs 1 extract + 1 compare + 2 xor + 2 or instead of the 9 operations hipcc
+        // makes of `peers &= bit ? m : ~m`.
+        unsigned int diff_lo = 0u, diff_hi = 0u;
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
-            const unsigned long long m = __ballot((d >> b) & 1);
-            peers &= ((d >> b) & 1) ? m : ~m;
+            const unsigned int rep = (unsigned int)__builtin_amdgcn_sbfe(d, b, 1); // 0 or 0xFFFFFFFF
+            const unsigned long long m = __ballot(rep != 0u);
+            diff_lo |= (unsigned int)m ^ rep;
+            diff_hi |= (unsigned int)(m >> 32) ^ rep;
         }
+        unsigned long long peers = ~(((unsigned long long)diff_hi << 32) | diff_lo) & __ballot(valid);
         if (!valid) peers = 0ull; // invalid lanes rank nothing
         const int before = __popcll(peers & lt_mask);
-        const int count = __popcll(peers);
-        int old = 0;
-        const int leader = peers ? __ffsll((long long)peers) - 1 : 0;
-        if (valid && lane == leader) {
-            old = s_wcnt[w][d];
-            s_wcnt[w][d] = old + count;
-        }
-        old = __shfl(old, leader, 64);
+        // every lane reads its digit's running count (lanes of one digit read the same word: an LDS broadcast), then the
+        // first of them adds the group's size -- a wave's LDS operations execute in order, so no lane sees the update early
+        const int old = valid ? s_wcnt[w][d] : 0;
+        if (valid && before == 0) s_wcnt[w][d] = old + __popcll(peers);
         rank[r] = old + before;
     }
     __syncthreads();
