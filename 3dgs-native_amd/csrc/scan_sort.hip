@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     __shared__ int s_off[4][64];
     __shared__ TileRect s_rect[4][64];
     __shared__ uint32_t s_gid[4][64];
+    __shared__ float s_inv[4][64]; // 1 / (rectangle width in tiles)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t k0 = (int64_t)blockIdx.x * 256 + w * 64;
     const int64_t k = k0 + lane;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     s_off[w][lane] = off;
     s_rect[w][lane] = rc;
     s_gid[w][lane] = id;
+    s_inv[w][lane] = rc.x1 > rc.x0 ? 1.0f / (float)((int)rc.x1 - (int)rc.x0) : 0.0f;
     __syncthreads();
     if (k0 >= n) return;
     const int begin = s_off[w][0];
@@ -379,7 +381,13 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
         const TileRect r = s_rect[w][lo];
         const int t = j - s_off[w][lo];
         const int wd = (int)r.x1 - (int)r.x0;
-        const int y = t / wd, x = t - y * wd; // row-major walk: y outer, x inner (reference forward.py:546-548)
+        // row-major walk: y = t / wd, x = t % wd (reference forward.py:546-548).  t < 2^24 (a rectangle has at most
+        // 4096 x 4096 tiles), so the quotient comes from one float multiply by the Gaussian's 1/wd and a +-1 correction
+        // instead of the ~25-instruction integer division
+        int y = (int)((float)t * s_inv[w][lo]);
+        int x = t - y * wd;
+        if (x < 0) { --y; x += wd; }
+        else if (x >= wd) { ++y; x -= wd; }
         tile_items[j] = (ItemT)(((ItemT)(uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x) << id_shift) | (ItemT)s_gid[w][lo]);
     }
 }
