@@ -88,7 +88,7 @@ __device__ __forceinline__ float edge_min_q(float qa, float qb, float qc, float 
 __device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float opacity, float x0, float y0, float ex, float ey)
 {
     if (!(opacity * 255.0f >= 1.0f)) return false;
-    const float tau = __logf(opacity * 255.0f); // >= 0
+    const float tau = __builtin_amdgcn_logf(opacity * 255.0f) * 0.6931471805599453f; // ln via v_log_f32 (argument >= 1: no denormal path); >= 0
     // d = g - pixel, pixel in [x0, x0+ex] -> d in [gx-x0-ex, gx-x0]
     const float dxl = gx - (x0 + ex), dxh = gx - x0, dyl = gy - (y0 + ey), dyh = gy - y0;
     float qmin;
@@ -178,7 +178,10 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             if (idx >= lo) {
                 id = point_list[idx];
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
-                const float4 a = rp[0], b = rp[1];
+                float4 a = rp[0], b = rp[1];
+                // both 16-byte loads complete here: left alone, hipcc sinks the first one below the opacity test of
+                // block_may_hit and the fill loop pays three dependent memory round trips per iteration instead of two
+                asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y));
                 hit = block_may_hit(a.x, a.y, a.z, a.w, b.x, b.y, fx0, fy0, (float)(BW - 1), (float)(BH - 1));
             }
             const unsigned long long m = __ballot(hit);

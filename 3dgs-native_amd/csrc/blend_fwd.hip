@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             s_c[tid] = make_float2(c.x, c.y);
             int m = 0;
             if (b.y * 255.0f >= 1.0f) {
-                const float lim = __logf(b.y * 255.0f) * 1.0001f + 1e-3f;
+                const float lim = __builtin_amdgcn_logf(b.y * 255.0f) * 0.6931471805599453f * 1.0001f + 1e-3f; // ln via v_log_f32, argument >= 1
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (block_may_hit(a.x, a.y, a.z, a.w, b.x, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 8))) m |= 1 << k;
