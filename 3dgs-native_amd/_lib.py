@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "libgsr_hip.so"))   # GSR_LIB: A/B runs of two builds on one box
 
 GSR_OK, GSR_E_NULL, GSR_E_DIMS, GSR_E_OVERFLOW, GSR_E_WORKSPACE, GSR_E_HIP, GSR_E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 
