@@ -80,13 +80,9 @@ def exchange_factored(arena, payload, average=True):
         return payload.unsqueeze(0)
     world = dist.get_world_size()
     gathered = torch.empty((world, payload.numel()), dtype=payload.dtype, device=payload.device)
-    if dist.get_backend() == "nccl":
-        work = dist.all_gather_into_tensor(gathered.view(-1), payload.contiguous(), async_op=True)   # the two run back to back
-        reduce_gradients(arena, world, average)
-        work.wait()
-    else:   # gloo (CPU tests, single-device rehearsals)
-        dist.all_gather([gathered[v] for v in range(world)], payload.contiguous())
-        reduce_gradients(arena, world, average)
+    work = dist.all_gather_into_tensor(gathered.view(-1), payload.contiguous(), async_op=True)   # the two run back to back
+    reduce_gradients(arena, world, average)
+    work.wait()
     return gathered
 
 
@@ -111,10 +107,7 @@ class FactoredExchange:
             return
         world = dist.get_world_size()
         self._gathered = torch.empty((world, payload.numel()), dtype=payload.dtype, device=payload.device)
-        if dist.get_backend() == "nccl":
-            self._work = dist.all_gather_into_tensor(self._gathered.view(-1), payload, async_op=True)
-        else:
-            self._work = dist.all_gather([self._gathered[v] for v in range(world)], payload, async_op=True)
+        self._work = dist.all_gather_into_tensor(self._gathered.view(-1), payload.contiguous(), async_op=True)
 
     def finish(self, grads, means3D, degree=3, average=True, out=None):
         """Returns the dict of the five averaged (or summed) optimizer gradients."""
