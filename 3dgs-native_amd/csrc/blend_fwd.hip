@@ -93,9 +93,19 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             int m = 0;
             if (b.y * 255.0f >= 1.0f) {
                 const float lim = __builtin_amdgcn_logf(b.y * 255.0f) * 0.6931471805599453f * 1.0001f + 1e-3f; // ln via v_log_f32, argument >= 1
+                // axis-aligned box of the ellipse q <= lim (half-widths sqrt(2 lim c / det), sqrt(2 lim a / det), padded): a block
+                // outside it cannot be hit, and only the blocks inside get the exact rectangle test
+                const float det = a.z * b.x - a.w * a.w;
+                const bool boxless = !(det > 0.0f); // not a proper ellipse (never for a valid conic): exact tests for every block
+                const float kdet = 2.0f * lim * fast_rcp(det);
+                const float hx = __builtin_amdgcn_sqrtf(kdet * b.x) * 1.001f + 0.05f, hy = __builtin_amdgcn_sqrtf(kdet * a.z) * 1.001f + 0.05f;
+                const float lx = a.x - hx - tx0, rx = a.x + hx - tx0, ly = a.y - hy - ty0, ry = a.y + hy - ty0; // box relative to the tile origin
+                const bool xin[2] = {boxless || (lx <= 7.0f && rx >= 0.0f), boxless || (lx <= 15.0f && rx >= 8.0f)};
+                const bool yin[2] = {boxless || (ly <= 7.0f && ry >= 0.0f), boxless || (ly <= 15.0f && ry >= 8.0f)};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (block_may_hit(a.x, a.y, a.z, a.w, b.x, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 8))) m |= 1 << k;
+                    if (xin[k & 1] && yin[k >> 1] &&
+                        block_may_hit(a.x, a.y, a.z, a.w, b.x, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 8))) m |= 1 << k;
             }
             s_mask[tid] = m;
         }
