@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "libgsr_hip.so"))   # GSR_LIB: A/B runs of two builds on one box
 
-GSR_OK, GSR_E_NULL, GSR_E_DIMS, GSR_E_OVERFLOW, GSR_E_WORKSPACE, GSR_E_HIP, GSR_E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+GSR_OK, GSR_E_NULL, GSR_E_DIMS, GSR_E_OVERFLOW, GSR_E_WORKSPACE, GSR_E_HIP, GSR_E_CAPACITY, GSR_E_ALIGN = 0, -1, -2, -3, -4, -5, -6, -7
 
 vp = C.c_void_p
 
@@ -61,6 +61,7 @@ MARK_CLONE, MARK_SPLIT = 0, 1
 EXPORTS = {
     "gsr_abi_version": (C.c_int, []),
     "gsr_strerror": (C.c_char_p, [C.c_int]),
+    "gsr_build_flags": (C.c_int, []),
     "gsr_geom_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gsr_binning_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "gsr_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
@@ -114,6 +115,13 @@ def lib():
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib
+
+
+def build_hash():
+    """First 16 hex digits of the SHA-256 of the loaded library file: the key under which profiles/ stores per-build counters."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def strerror(code):

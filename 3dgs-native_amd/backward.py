@@ -3,8 +3,8 @@ backward(): the reference's gradient call surface (reference backward.py:955-119
 library.  Same keyword arguments and the same nine-key return dict (`dL_dcov3D` is all zeros, as in
 the reference, whose real dL/dSigma3D is a local that never leaves backward_preprocess, :812/:1119).
 The five optimizer gradients are views into one flat float32 arena (`_arena`, 59 floats per
-Gaussian: mean3D | scale | rot | opacity | shs) so data-parallel training reduces them with a single
-RCCL all-reduce.
+Gaussian: mean3D | scale | rot | opacity | shs, each segment padded to a multiple of 4 floats, dist.arena_offsets) so
+data-parallel training reduces them with a single RCCL all-reduce.
 
 One keyword beyond the reference's: `sh_gradient="factored"` (view-parallel training, dist.py) leaves the 48-float SH
 gradient unwritten and returns instead the 3-float colour gradient it is an outer product of, as a self-contained view
@@ -20,18 +20,17 @@ import torch
 from . import _host, _lib
 
 
-_ZERO_COV = {}
+_ZERO = {}
 
 
 def _zeros_cov3d(n, dev):
-    """The reference returns an all-zero dL_dcov3D (backward.py:1119 is never filled); hand out one shared,
-    read-only-by-convention zero tensor per (N, device) instead of clearing 24*N bytes every call."""
-    key = (n, dev.index)
-    t = _ZERO_COV.get(key)
-    if t is None:
-        _ZERO_COV.clear()
-        t = _ZERO_COV[key] = torch.zeros((n, 6), dtype=torch.float32, device=dev)
-    return t
+    """The reference returns an all-zero dL_dcov3D (backward.py:1119 is never filled).  Instead of clearing 24*N bytes every
+    call this is a stride-0 expansion of ONE zero scalar per device: reads (`.cpu().numpy()`, copies) see (N, 6) zeros, and an
+    in-place write raises instead of silently corrupting what later calls return."""
+    z = _ZERO.get(dev.index)
+    if z is None:
+        z = _ZERO[dev.index] = torch.zeros((), dtype=torch.float32, device=dev)
+    return z.expand(n, 6)
 
 
 def _get(buf, key):
@@ -90,21 +89,24 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges))
     img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
 
-    o = [0, 3 * N, 6 * N, 10 * N, 11 * N, 59 * N]
+    from . import dist as _dist
+    o = _dist.arena_offsets(N, small=factored)     # every segment starts on a multiple of 4 floats (16-byte vector stores)
     payload = None
+    arena = torch.empty(o[-1], dtype=f32, device=dev)
+    if N % 4:                                      # the <= 3 padding floats behind a segment: defined (zero), never garbage
+        for k, sz in enumerate([3 * N, 3 * N, 4 * N, N][:len(o) - 2]):
+            arena[o[k] + sz:o[k + 1]].zero_()
     if factored:
-        arena = torch.empty(N * 11, dtype=f32, device=dev)
         payload = torch.empty(N * 3 + 4, dtype=f32, device=dev)   # its own allocation: aligned for the collective
         dL_dsh = None
     else:
-        arena = torch.empty(N * 59, dtype=f32, device=dev)
-        dL_dsh = arena[o[4]:o[5]].view(N * 16, 3)   # always N*16 rows: the reference under-allocates for degree < 3 (quirk Q6)
+        dL_dsh = arena[o[4]:o[4] + 48 * N].view(N * 16, 3)   # always N*16 rows: the reference under-allocates for degree < 3 (quirk Q6)
         if sh_gradient == "both":                   # dense gradient AND the payload it factors into (tests, debugging)
             payload = torch.empty(N * 3 + 4, dtype=f32, device=dev)
-    dL_dmean3D = arena[o[0]:o[1]].view(N, 3)
-    dL_dscale = arena[o[1]:o[2]].view(N, 3)
-    dL_drot = arena[o[2]:o[3]].view(N, 4)
-    dL_dopacity = arena[o[3]:o[4]]
+    dL_dmean3D = arena[o[0]:o[0] + 3 * N].view(N, 3)
+    dL_dscale = arena[o[1]:o[1] + 3 * N].view(N, 3)
+    dL_drot = arena[o[2]:o[2] + 4 * N].view(N, 4)
+    dL_dopacity = arena[o[3]:o[3] + N]
     dL_dcolor = torch.empty((N, 3), dtype=f32, device=dev)
     dL_dmean2D = torch.empty((N, 3), dtype=f32, device=dev)
     dL_dconic = torch.empty((N, 4), dtype=f32, device=dev)

@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "gsr_internal.h"
 
@@ -79,6 +82,9 @@ int check_scene_cam(const GsrScene *sc, const GsrCamera *cam)
     if (sc->N < 0 || sc->N > 0x7FFFFFFFLL || cam->W <= 0 || cam->H <= 0 || sc->sh_degree < 0 || sc->sh_degree > 3) return GSR_E_DIMS;
     if ((cam->W + 15) / 16 > 65535 || (cam->H + 15) / 16 > 65535) return GSR_E_DIMS;
     if (sc->N > 0 && (!sc->means || !sc->scales || !sc->rotations || !sc->opacity || !sc->sh)) return GSR_E_NULL;
+    if (!gsr_aligned16(sc->means) || !gsr_aligned16(sc->scales) || !gsr_aligned16(sc->rotations) || !gsr_aligned16(sc->opacity) ||
+        !gsr_aligned16(sc->sh))
+        return GSR_E_ALIGN;
     return GSR_OK;
 }
 
@@ -100,6 +106,19 @@ CamK make_cam(const GsrCamera *c)
     return k;
 }
 
+bool geom_aligned(const GsrGeom *g)
+{
+    return gsr_aligned16(g->radii) && gsr_aligned16(g->tiles_touched) && gsr_aligned16(g->point_offsets) && gsr_aligned16(g->xy) &&
+           gsr_aligned16(g->depths) && gsr_aligned16(g->cov3D) && gsr_aligned16(g->rgb) && gsr_aligned16(g->conic_opacity) &&
+           gsr_aligned16(g->clamped_state) && gsr_aligned16(g->blend_records);
+}
+bool grads_aligned(const GsrGrads *g)
+{
+    return gsr_aligned16(g->dL_dmean3D) && gsr_aligned16(g->dL_dscale) && gsr_aligned16(g->dL_drot) && gsr_aligned16(g->dL_dopacity) &&
+           gsr_aligned16(g->dL_dshs) && gsr_aligned16(g->dL_dcolor) && gsr_aligned16(g->dL_dmean2D) && gsr_aligned16(g->dL_dconic) &&
+           gsr_aligned16(g->dL_drgb);
+}
+
 bool geom_ok(const GsrGeom *g)
 {
     return g && g->radii && g->tiles_touched && g->point_offsets && g->xy && g->depths && g->cov3D && g->rgb && g->conic_opacity &&
@@ -107,49 +126,138 @@ bool geom_ok(const GsrGeom *g)
 }
 
 // ---- stage timing (profiling aid) ----
+// Process-wide by design (one benchmark drives it); `on` is atomic so the hot path pays one relaxed load when it is off,
+// and every read-modify-write of the counters happens under g_timer_mu, so host threads driving different streams may
+// all run with timing enabled (their samples interleave in the one record).
 struct StageTimer {
-    bool on = false;
+    std::atomic<bool> on{false};
     int max_steps = 0, fwd_step = 0, bwd_step = 0; // recorded (sampled) steps so far
     int every = 1, fwd_calls = 0, bwd_calls = 0;    // record one call in `every`; event records cost ~3 us each
-    bool fwd_sampled = false, split_sampled = false;
     hipEvent_t *ev = nullptr; // [max_steps][GSR_NSTAGES + 3]
     static constexpr int PER = GSR_NSTAGES + 3;
     hipEvent_t &at(int step, int k) { return ev[(size_t)step * PER + k]; }
 } g_timer;
+std::mutex g_timer_mu;
 // event slots: 0..9 forward boundaries (before stage 0 .. after stage 8, with slot 3 = after sync),
 // 10..13 backward boundaries
 inline void mark(int step, int slot, hipStream_t s)
 {
     if (step >= 0 && step < g_timer.max_steps) (void)hipEventRecord(g_timer.at(step, slot), s);
 }
+// which record (if any) a call samples into: -1 = not sampled.  The forward's two entry points share one record, as do
+// the two halves of a split backward; the step is carried between them per host thread.
+thread_local int t_fwd_record = -1, t_bwd_record = -1;
+int timer_open(bool forward)
+{
+    if (!g_timer.on.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if (!g_timer.on.load(std::memory_order_relaxed)) return -1;
+    int &calls = forward ? g_timer.fwd_calls : g_timer.bwd_calls;
+    int &step = forward ? g_timer.fwd_step : g_timer.bwd_step;
+    if ((calls++ % g_timer.every) != 0 || step >= g_timer.max_steps) return -1;
+    return step++;
+}
 
-// Per-device readback slot for D: 4 bytes of pinned host memory + an event, created on first use and
-// kept for the life of the process.  With them the host can wait for D alone while the GPU already
-// runs the depth sort, which does not depend on D.
+// ---- readback slots for D ----
+// 4 bytes of pinned host memory + an event per call IN FLIGHT: gsr_forward_count leases a slot of its device from this
+// pool and returns it before it returns, so two host threads counting on the same device never share a word, and a
+// thread that exits leaks nothing (slots are created on demand and kept for the life of the process).  With the pinned
+// word the host can wait for D alone while the GPU already runs the depth sort, which does not depend on D.
 struct Readback {
+    int dev = -1;
+    bool busy = false;
     int32_t *pinned = nullptr;
     hipEvent_t ev = nullptr;
 };
-Readback *readback_slot()
+std::mutex g_rb_mu;
+std::vector<Readback *> g_rb_pool;
+Readback *readback_acquire()
 {
-    static thread_local Readback slots[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    Readback &r = slots[dev];
-    if (!r.pinned) {
-        if (hipHostMalloc((void **)&r.pinned, 64, hipHostMallocMapped) != hipSuccess) return nullptr; // device-writable
-        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_rb_mu);
+    for (Readback *r : g_rb_pool)
+        if (r->dev == dev && !r->busy) {
+            r->busy = true;
+            return r;
+        }
+    Readback *r = new Readback;
+    r->dev = dev;
+    if (hipHostMalloc((void **)&r->pinned, 64, hipHostMallocMapped) != hipSuccess ||       // device-writable
+        hipEventCreateWithFlags(&r->ev, hipEventDisableTiming) != hipSuccess) {
+        if (r->pinned) (void)hipHostFree(r->pinned);
+        delete r;
+        return nullptr;
     }
-    return &r;
+    r->busy = true;
+    g_rb_pool.push_back(r);
+    return r;
+}
+struct ReadbackLease {
+    Readback *r;
+    ReadbackLease() : r(readback_acquire()) {}
+    ~ReadbackLease()
+    {
+        if (!r) return;
+        std::lock_guard<std::mutex> lk(g_rb_mu);
+        r->busy = false;
+    }
+};
+
+// ---- the count gsr_forward_count returned, per geom workspace ----
+// gsr_forward_render trusts nothing about GsrBinning.D that it can check: the expansion, both partition passes and the
+// range scan are sized by D, and a D that is not the count of the depth-sorted items in geom_ws would make them write out
+// of bounds (too large) or truncate the list silently (too small).  The true count never leaves the host, so it is
+// remembered here, keyed by (device, geom_ws); a small LRU table, guarded by a mutex.
+struct CountNote {
+    int dev;
+    const void *ws;
+    int64_t N, D;
+    uint64_t stamp;
+};
+std::mutex g_note_mu;
+std::vector<CountNote> g_notes;
+uint64_t g_note_clock = 0;
+constexpr size_t MAX_NOTES = 256;
+void note_count(const void *ws, int64_t N, int64_t D)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_note_mu);
+    CountNote *slot = nullptr;
+    for (CountNote &c : g_notes)
+        if (c.dev == dev && c.ws == ws) slot = &c;
+    if (!slot) {
+        if (g_notes.size() < MAX_NOTES) {
+            g_notes.push_back(CountNote{});
+            slot = &g_notes.back();
+        } else {
+            slot = &*std::min_element(g_notes.begin(), g_notes.end(), [](const CountNote &a, const CountNote &b) { return a.stamp < b.stamp; });
+        }
+    }
+    *slot = CountNote{dev, ws, N, D, ++g_note_clock};
+}
+// 1 = matches, 0 = mismatch, -1 = this workspace has no recorded count
+int check_count(const void *ws, int64_t N, int64_t D)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_note_mu);
+    for (CountNote &c : g_notes)
+        if (c.dev == dev && c.ws == ws) {
+            c.stamp = ++g_note_clock;
+            return (c.N == N && c.D == D) ? 1 : 0;
+        }
+    return -1;
 }
 
+std::once_flag g_tuning_once;
 void read_tuning()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e);
-    if (const char *e = getenv("GSR_BWD_BLOCK")) gsr_bwd_block = atoi(e);
+    std::call_once(g_tuning_once, [] {
+        if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e) & GSR_DEBUG_ALLOWED;
+        if (const char *e = getenv("GSR_BWD_BLOCK")) gsr_bwd_block = atoi(e);
+    });
 }
 
 } // namespace
@@ -176,6 +284,15 @@ extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
+int gsr_build_flags(void)
+{
+#ifdef GSR_ABLATE
+    return GSR_BUILD_ABLATE;
+#else
+    return 0;
+#endif
+}
+
 const char *gsr_strerror(int code)
 {
     switch (code) {
@@ -185,7 +302,8 @@ const char *gsr_strerror(int code)
     case GSR_E_OVERFLOW: return "Number of rendered points exceeds the maximum supported (2^30)";
     case GSR_E_WORKSPACE: return "workspace missing or too small";
     case GSR_E_HIP: return "HIP runtime error (see stderr)";
-    case GSR_E_CAPACITY: return "binning capacity does not match the rendered count";
+    case GSR_E_CAPACITY: return "GsrBinning.D is not the count gsr_forward_count returned for this geom workspace";
+    case GSR_E_ALIGN: return "an array pointer is not 16-byte aligned";
     default: return "unknown error";
     }
 }
@@ -204,16 +322,17 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     const int64_t N = scene->N;
     if (N == 0) return GSR_OK; // reference behaviour undefined (quirk Q10): empty buffers, D = 0
     if (!geom_ok(geom)) return GSR_E_NULL;
+    if (!geom_aligned(geom) || !gsr_aligned16(geom_ws)) return GSR_E_ALIGN;
     if (!geom_ws || geom_ws_bytes < gsr_geom_workspace_bytes(N)) return GSR_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const CamK cam = make_cam(camera);
     const GeomWs ws = gsr_carve_geom(geom_ws, N);
-    g_timer.fwd_sampled = g_timer.on && (g_timer.fwd_calls++ % g_timer.every) == 0;
-    const int st = g_timer.fwd_sampled ? g_timer.fwd_step : -1;
+    const int st = t_fwd_record = timer_open(true);
     mark(st, 0, s);
     HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s));
     mark(st, 1, s);
-    Readback *rb = readback_slot();
+    ReadbackLease lease;
+    Readback *rb = lease.r;
     if (!rb) return GSR_E_HIP;
     // the scan's last wave stores D = point_offsets[N-1] straight into the pinned host word
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, s));
@@ -238,6 +357,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     const int32_t last = *rb->pinned;
     *num_rendered = (int64_t)last;
     if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
+    note_count(geom_ws, N, (int64_t)last);
     return GSR_OK;
 }
 
@@ -255,6 +375,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const size_t P = (size_t)cam.W * cam.H;
     const int tiles = cam.grid_x * cam.grid_y;
     if (D == 0 || N == 0) { // reference skips the blend: zeros, not background (forward.py:830, quirk Q10)
+        t_fwd_record = -1;  // a sampled record that ends here stays incomplete and is dropped by gsr_stage_times
         HIP_TRY(hipMemsetAsync(binning->ranges, 0, sizeof(int32_t) * 2 * tiles, s));
         HIP_TRY(hipMemsetAsync(image->image, 0, P * 3 * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(image->inv_depth, 0, P * sizeof(float), s));
@@ -263,12 +384,19 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
         return GSR_OK;
     }
     if (!geom_ok(geom) || !binning->point_list) return GSR_E_NULL;
+    if (!geom_aligned(geom) || !gsr_aligned16(geom_ws) || !gsr_aligned16(bin_ws) || !gsr_aligned16(binning->point_list) ||
+        !gsr_aligned16(binning->ranges) || !gsr_aligned16(image->image) || !gsr_aligned16(image->inv_depth) ||
+        !gsr_aligned16(image->final_T) || !gsr_aligned16(image->n_contrib))
+        return GSR_E_ALIGN;
     if (!geom_ws || geom_ws_bytes < gsr_geom_workspace_bytes(N)) return GSR_E_WORKSPACE;
     if (!bin_ws || bin_ws_bytes < gsr_binning_workspace_bytes(N, D, cam.W, cam.H)) return GSR_E_WORKSPACE;
+    // D must be the count gsr_forward_count returned for the items now in geom_ws (see CountNote above)
+    if (check_count(geom_ws, N, D) != 1) return GSR_E_CAPACITY;
     const GeomWs gw = gsr_carve_geom(geom_ws, N);
     const BinWs bw = carve_bin(bin_ws, N, D);
 
-    const int st = g_timer.fwd_sampled ? g_timer.fwd_step : -1;
+    const int st = t_fwd_record;
+    t_fwd_record = -1;
     mark(st, 5, s);
     // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile << id_shift | id) items.  When the tile
     //    bits and the id bits fit one 32-bit word (800x800 with 1M Gaussians: 12 + 20) the items are uint32, which
@@ -296,7 +424,6 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     mark(st, 8, s);
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, s));
     mark(st, 9, s);
-    if (g_timer.fwd_sampled) ++g_timer.fwd_step;
     return GSR_OK;
 }
 
@@ -307,6 +434,9 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
     const int64_t N = scene->N;
     if (!geom || !geom->radii || !geom->xy || !geom->cov3D || !geom->rgb || !geom->conic_opacity || !geom->clamped_state) return GSR_E_NULL;
     if (!binning || !image || !dL_dpixels) return GSR_E_NULL;
+    if (!geom_aligned(geom) || !gsr_aligned16(ws) || !gsr_aligned16(binning->point_list) || !gsr_aligned16(binning->ranges) ||
+        !gsr_aligned16(image->final_T) || !gsr_aligned16(image->n_contrib) || !gsr_aligned16(dL_dpixels) || !gsr_aligned16(payload))
+        return GSR_E_ALIGN;
     const int64_t D = binning->D;
     if (D < 0 || D > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
     if (D > 0 && (!binning->point_list || !binning->ranges || !image->final_T || !image->n_contrib)) return GSR_E_NULL;
@@ -337,6 +467,7 @@ static int backward_geom_impl(const GsrScene *scene, const GsrCamera *camera, co
         !grads->dL_dmean2D || !grads->dL_dconic)
         return GSR_E_NULL;
     if (!geom || !geom->radii || !geom->cov3D || !geom->clamped_state) return GSR_E_NULL;
+    if (!geom_aligned(geom) || !grads_aligned(grads) || !gsr_aligned16(ws)) return GSR_E_ALIGN;
     if (!ws || ws_bytes < gsr_backward_workspace_bytes(N, 0, camera->W, camera->H)) return GSR_E_WORKSPACE;
     const CamK cam = make_cam(camera);
     const BwdWs bw = carve_bwd(ws, N);
@@ -355,11 +486,9 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
         !grads->dL_dcolor || !grads->dL_dmean2D || !grads->dL_dconic)
         return GSR_E_NULL;
     hipStream_t s = (hipStream_t)stream;
-    const bool bwd_sampled = g_timer.on && (g_timer.bwd_calls++ % g_timer.every) == 0;
-    const int st = bwd_sampled ? g_timer.bwd_step : -1;
+    const int st = timer_open(false);
     if (int rc = backward_blend_impl(scene, camera, geom, binning, image, dL_dpixels, nullptr, ws, ws_bytes, s, st)) return rc;
     if (int rc = backward_geom_impl(scene, camera, geom, grads, ws, ws_bytes, s, st)) return rc;
-    if (bwd_sampled) ++g_timer.bwd_step;
     return GSR_OK;
 }
 
@@ -370,9 +499,8 @@ int gsr_backward_blend(const GsrScene *scene, const GsrCamera *camera, const Gsr
     if (int rc = check_scene_cam(scene, camera)) return rc;
     if (scene->N == 0) return GSR_OK;
     // stage events: the two halves of one backward share a record; it is opened here and closed by gsr_backward_geom
-    g_timer.split_sampled = g_timer.on && (g_timer.bwd_calls++ % g_timer.every) == 0;
-    return backward_blend_impl(scene, camera, geom, binning, image, dL_dpixels, payload, ws, ws_bytes, (hipStream_t)stream,
-                               g_timer.split_sampled ? g_timer.bwd_step : -1);
+    t_bwd_record = timer_open(false);
+    return backward_blend_impl(scene, camera, geom, binning, image, dL_dpixels, payload, ws, ws_bytes, (hipStream_t)stream, t_bwd_record);
 }
 
 int gsr_backward_geom(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, const GsrGrads *grads, void *ws, size_t ws_bytes,
@@ -381,15 +509,14 @@ int gsr_backward_geom(const GsrScene *scene, const GsrCamera *camera, const GsrG
     read_tuning();
     if (int rc = check_scene_cam(scene, camera)) return rc;
     if (scene->N == 0) return GSR_OK;
-    const bool sampled = g_timer.split_sampled;
-    g_timer.split_sampled = false;
-    if (int rc = backward_geom_impl(scene, camera, geom, grads, ws, ws_bytes, (hipStream_t)stream, sampled ? g_timer.bwd_step : -1)) return rc;
-    if (sampled) ++g_timer.bwd_step;
-    return GSR_OK;
+    const int st = t_bwd_record;
+    t_bwd_record = -1;
+    return backward_geom_impl(scene, camera, geom, grads, ws, ws_bytes, (hipStream_t)stream, st);
 }
 
 int gsr_stage_timing(int enable, int max_steps)
 {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
     if (g_timer.ev) {
         for (size_t i = 0; i < (size_t)g_timer.max_steps * StageTimer::PER; ++i) (void)hipEventDestroy(g_timer.ev[i]);
         free(g_timer.ev);
@@ -411,6 +538,7 @@ int gsr_stage_timing(int enable, int max_steps)
 int gsr_stage_sampling(int every)
 {
     if (every < 1) return GSR_E_DIMS;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
     g_timer.every = every;
     return GSR_OK;
 }
@@ -418,24 +546,29 @@ int gsr_stage_sampling(int every)
 int gsr_stage_times(float *avg_ms, int *steps)
 {
     if (!avg_ms || !steps) return GSR_E_NULL;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
     for (int k = 0; k < GSR_NSTAGES; ++k) avg_ms[k] = 0.0f;
     int n = g_timer.fwd_step < g_timer.bwd_step ? g_timer.fwd_step : g_timer.bwd_step;
     if (n > g_timer.max_steps) n = g_timer.max_steps;
     *steps = n;
-    if (!g_timer.on || n == 0) return GSR_OK;
-    // stage k of the forward lies between event slots k and k+1 (k = 0..8); backward stages 9..11 between 10+j and 11+j
+    if (!g_timer.on.load() || n == 0) return GSR_OK;
+    // stage k of the forward lies between event slots k and k+1 (k = 0..8); backward stages 9..11 between 10+j and 11+j.
+    // A record whose call ended early (an error return, D == 0) has unrecorded events: it is left out.
+    int used = 0;
     for (int st = 0; st < n; ++st) {
-        for (int k = 0; k < 9; ++k) {
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, g_timer.at(st, k), g_timer.at(st, k + 1)));
-            avg_ms[k] += ms;
+        float ms[GSR_NSTAGES];
+        bool whole = true;
+        for (int k = 0; k < 9 && whole; ++k) whole = hipEventElapsedTime(&ms[k], g_timer.at(st, k), g_timer.at(st, k + 1)) == hipSuccess;
+        for (int j = 0; j < 3 && whole; ++j) whole = hipEventElapsedTime(&ms[9 + j], g_timer.at(st, 10 + j), g_timer.at(st, 11 + j)) == hipSuccess;
+        if (!whole) {
+            (void)hipGetLastError();
+            continue;
         }
-        for (int j = 0; j < 3; ++j) {
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, g_timer.at(st, 10 + j), g_timer.at(st, 11 + j)));
-            avg_ms[9 + j] += ms;
-        }
+        for (int k = 0; k < GSR_NSTAGES; ++k) avg_ms[k] += ms[k];
+        ++used;
     }
+    *steps = n = used;
+    if (n == 0) return GSR_OK;
     for (int k = 0; k < GSR_NSTAGES; ++k) avg_ms[k] /= (float)n;
     g_timer.fwd_step = g_timer.bwd_step = 0;
     return GSR_OK;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, S1 = 0.f, S2 = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sop = 0.f;
         bool touched = false;
 
-        for (int q = 0; q < ((dbg & 2) ? 1 : NPIX); ++q) {
+        for (int q = 0; q < (GSR_ABL(dbg, 2) ? 1 : NPIX); ++q) {
             const float4 pb = s_pb[q];
             const int pkept = __float_as_int(pb.w);
             if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         for (int r = 0; r < 16; ++r) {
             const int e = r * 4 + (lane >> 4);
             const int eid = s_id[e];
-            if (c < 9 && eid >= 0 && !(dbg & 1)) unsafeAtomicAdd(&acc[eid].f[c], s_g[e][c]);
+            if (c < 9 && eid >= 0 && !GSR_ABL(dbg, 1)) unsafeAtomicAdd(&acc[eid].f[c], s_g[e][c]);
         }
         __syncthreads();
     }
@@ -303,7 +303,7 @@ hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, h
 }
 
 int gsr_bwd_block = 32;
-int gsr_debug_flags = 0; // GSR_DEBUG: bit0 = skip atomics, bit1 = one pixel per bucket (timing ablations only)
+int gsr_debug_flags = 0; // see gsr_internal.h
 
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
                                            const GsrImage &img, const float *dL_dpixels, GradRec *acc, hipStream_t s)

@@ -450,6 +450,7 @@ extern "C" int gsr_sh_grad_from_views(int64_t N, const float *means, int32_t sh_
     if (N < 0 || V < 1 || V > GSR_MAX_VIEWS || sh_degree < 0 || sh_degree > 3 || N > ((int64_t)1 << 27)) return GSR_E_DIMS;
     if (N == 0) return GSR_OK;
     if (!means || !payloads || !dL_dshs) return GSR_E_NULL;
+    if (!gsr_aligned16(dL_dshs)) return GSR_E_ALIGN; // payload rows are read as scalars: rows of a gathered [V][3N+4] block are fine
     ViewSet vs;
     for (int v = 0; v < GSR_MAX_VIEWS; ++v) {
         vs.payload[v] = v < V ? payloads[v] : nullptr;

@@ -29,6 +29,7 @@ struct __attribute__((aligned(8))) TileRect {
     uint16_t x0, y0, x1, y1;
 };
 
+static inline bool gsr_aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; } // null counts as aligned
 static inline int64_t gsr_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -89,6 +90,16 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
-extern int gsr_debug_flags;        // GSR_DEBUG    : bits 0-3 timing ablations (wrong results); bit 5 forces 64-bit tile items, bit 6 the
-                                   //                large-n radix chunks (same results: tests/test_gpu_alt_paths.py); never set in production
+// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks -- same results by
+// other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
+// one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->
+// libgsr_hip_ablate.so, -DGSR_ABLATE, used by tools/stage_bench.sh) and are compiled out of libgsr_hip.so.
+#ifdef GSR_ABLATE
+#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64)
+#define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define GSR_DEBUG_ALLOWED (32 | 64)
+#define GSR_ABL(flags, bit) false
+#endif
+extern int gsr_debug_flags;
 extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)

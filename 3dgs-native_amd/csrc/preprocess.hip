@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     // near plane with the centre within 1.1x the image.  The rare visible Gaussian that fails this guess (a big one
     // centred far outside) gets its row in a second, late fetch below, so the guess only affects speed.
     const bool likely = in_range && !(p_view[2] < 0.2f) && fabsf(ndc_x) <= 1.1f && fabsf(ndc_y) <= 1.1f;
-    const unsigned long long early_mask = (dbg & 4) ? 0ull : __ballot(likely);
+    const unsigned long long early_mask = GSR_ABL(dbg, 4) ? 0ull : __ballot(likely);
     ShRegs sh_regs;
     sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, early_mask);
     if (!(p_view[2] < 0.2f)) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     sh_rows_commit(sh_regs, lds_wave, lane);
     // in_range: tail lanes redo the last Gaussian; their rows do not exist (found by tests/test_gpu_fuzz.py: N = 1, one big
     // splat centred outside the frustum -> 63 rows read past the end of the SH array)
-    const unsigned long long late_mask = (dbg & 4) ? 0ull : (__ballot(need_sh && in_range) & ~early_mask);
+    const unsigned long long late_mask = GSR_ABL(dbg, 4) ? 0ull : (__ballot(need_sh && in_range) & ~early_mask);
     if (late_mask) { // wave-uniform and rare
         sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, late_mask);
         sh_rows_commit_masked(sh_regs, lds_wave, lane, late_mask);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 }
     }
     if (!in_range) return;
-    if (dbg & 8) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
+    if (GSR_ABL(dbg, 8)) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
 
     radii[i] = o_radius;
     tiles_touched[i] = o_tiles;

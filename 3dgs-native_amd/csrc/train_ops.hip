@@ -215,6 +215,7 @@ int gsr_l1_loss_grad(const float *rendered, const float *target, float *pixel_gr
 {
     if (!rendered || !target || !loss_sum) return GSR_E_NULL;
     if (W <= 0 || H <= 0) return GSR_E_DIMS;
+    if (!gsr_aligned16(rendered) || !gsr_aligned16(target) || !gsr_aligned16(pixel_grad)) return GSR_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return GSR_E_HIP;
     const int64_t n = (int64_t)W * H * 3;
@@ -258,6 +259,8 @@ int gsr_adam_update(const GsrAdam *a, void *stream)
     if (a->N < 0) return GSR_E_DIMS;
     if (a->N == 0) return GSR_OK;
     if (!group_ok(a->pos) || !group_ok(a->scale) || !group_ok(a->rot) || !group_ok(a->opacity) || !group_ok(a->sh)) return GSR_E_NULL;
+    for (const GsrAdamGroup *g : {&a->pos, &a->scale, &a->rot, &a->opacity, &a->sh})
+        if (!gsr_aligned16(g->param) || !gsr_aligned16(g->grad) || !gsr_aligned16(g->m) || !gsr_aligned16(g->v)) return GSR_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     AdamK k;
     k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = a->epsilon;

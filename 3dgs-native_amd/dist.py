@@ -23,6 +23,7 @@ import torch.distributed as dist
 
 ARENA_FLOATS = 59
 SMALL_ARENA_FLOATS = 11      # mean3D | scale | rot | opacity (backward(..., sh_gradient="factored"))
+MAX_VIEWS_PER_CALL = 16      # GSR_MAX_VIEWS of include/gsr.h
 
 
 def init_from_env(backend=None, device=None):
@@ -42,12 +43,37 @@ def views_for_rank(num_views, rank, world_size):
     return list(range(rank, num_views, world_size))
 
 
+def arena_offsets(n, small=False):
+    """Float offsets of the segments mean3D | scale | rot | opacity [| shs] inside one flat arena, each segment starting on a
+    multiple of 4 floats: the kernels write dL_drot and the SH rows as 16-byte vectors, and include/gsr.h asks for 16-byte
+    aligned array pointers.  Returns the starts plus the total length ([5] small, [6] dense); for N % 4 == 0 these are the
+    plain 3N | 3N | 4N | N | 48N offsets.  The <= 3 padding floats between segments ride along in the collective."""
+    sizes = [3 * n, 3 * n, 4 * n, n] + ([] if small else [48 * n])
+    offs, o = [], 0
+    for sz in sizes:
+        offs.append(o)
+        o = (o + sz + 3) & ~3
+    return offs + [offs[-1] + sizes[-1]]
+
+
+def arena_size(n, small=False):
+    return arena_offsets(n, small)[-1]
+
+
+def _n_of_arena(arena, small):
+    per = SMALL_ARENA_FLOATS if small else ARENA_FLOATS
+    n = arena.numel() // per          # padding is < 16 floats in total, so it can only push the quotient up for tiny n
+    while n > 0 and arena_size(n, small) > arena.numel():
+        n -= 1
+    return n
+
+
 def arena_views(arena, n):
-    """Split a flat [59*n] arena into the five gradient arrays (views, no copies)."""
-    o = [0, 3 * n, 6 * n, 10 * n, 11 * n, 59 * n]
-    return {"dL_dmean3D": arena[o[0]:o[1]].view(n, 3), "dL_dscale": arena[o[1]:o[2]].view(n, 3),
-            "dL_drot": arena[o[2]:o[3]].view(n, 4), "dL_dopacity": arena[o[3]:o[4]],
-            "dL_dshs": arena[o[4]:o[5]].view(n * 16, 3)}
+    """Split a flat dense arena (arena_size(n) floats) into the five gradient arrays (views, no copies)."""
+    o = arena_offsets(n)
+    return {"dL_dmean3D": arena[o[0]:o[0] + 3 * n].view(n, 3), "dL_dscale": arena[o[1]:o[1] + 3 * n].view(n, 3),
+            "dL_drot": arena[o[2]:o[2] + 4 * n].view(n, 4), "dL_dopacity": arena[o[3]:o[3] + n],
+            "dL_dshs": arena[o[4]:o[4] + 48 * n].view(n * 16, 3)}
 
 
 def reduce_gradients(arena, world_size=None, average=True):
@@ -66,10 +92,10 @@ def reduce_gradients(arena, world_size=None, average=True):
 
 
 def small_arena_views(arena, n):
-    """Split the 11-float arena of the factored mode (views, no copies)."""
-    o = [0, 3 * n, 6 * n, 10 * n, 11 * n]
-    return {"dL_dmean3D": arena[o[0]:o[1]].view(n, 3), "dL_dscale": arena[o[1]:o[2]].view(n, 3),
-            "dL_drot": arena[o[2]:o[3]].view(n, 4), "dL_dopacity": arena[o[3]:o[4]]}
+    """Split the 11-float arena of the factored mode (arena_size(n, small=True) floats; views, no copies)."""
+    o = arena_offsets(n, small=True)
+    return {"dL_dmean3D": arena[o[0]:o[0] + 3 * n].view(n, 3), "dL_dscale": arena[o[1]:o[1] + 3 * n].view(n, 3),
+            "dL_drot": arena[o[2]:o[2] + 4 * n].view(n, 4), "dL_dopacity": arena[o[3]:o[3] + n]}
 
 
 def exchange_factored(arena, payload, average=True):
@@ -112,7 +138,7 @@ class FactoredExchange:
     def finish(self, grads, means3D, degree=3, average=True, out=None):
         """Returns the dict of the five averaged (or summed) optimizer gradients."""
         arena = grads["_arena"]
-        n = arena.numel() // SMALL_ARENA_FLOATS
+        n = _n_of_arena(arena, small=True)
         reduce_work = None
         if dist.is_initialized() and dist.get_world_size() > 1:
             if average and arena.is_cuda and dist.get_backend() == "nccl":
@@ -137,6 +163,8 @@ def sh_gradients_from_views(means3D, payloads, degree=3, average=True, out=None,
     `scale` overrides the factor (1/V when averaging) -- e.g. 1/batch when some rows are zero padding."""
     from . import _host, _lib
     rows = [payloads[v] for v in range(len(payloads))]
+    if not rows:
+        raise ValueError("sh_gradients_from_views: no view payloads")
     n = int(means3D.shape[0])
     dev = means3D.device
     for r in rows:
@@ -146,9 +174,19 @@ def sh_gradients_from_views(means3D, payloads, degree=3, average=True, out=None,
         raise ValueError("sh_gradients_from_views: means3D must be a contiguous float32 device tensor")
     if out is None:
         out = torch.empty((n * 16, 3), dtype=torch.float32, device=dev)
-    ptrs = (C.c_void_p * len(rows))(*[r.data_ptr() for r in rows])
+    factor = float(scale) if scale is not None else (1.0 / len(rows) if average else 1.0)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().gsr_sh_grad_from_views(n, _host.ptr(means3D), int(degree), len(rows), ptrs,
-                                                     float(scale) if scale is not None else (1.0 / len(rows) if average else 1.0),
-                                                     _host.ptr(out), _host.stream_ptr(dev)))
+        # the kernel takes at most GSR_MAX_VIEWS payload rows per call: larger batches are rebuilt in chunks and summed
+        tmp = None
+        for c0 in range(0, len(rows), MAX_VIEWS_PER_CALL):
+            chunk = rows[c0:c0 + MAX_VIEWS_PER_CALL]
+            if c0 == 0:
+                dst = out
+            else:
+                dst = tmp = torch.empty_like(out) if tmp is None else tmp
+            ptrs = (C.c_void_p * len(chunk))(*[r.data_ptr() for r in chunk])
+            _lib.check(_lib.lib().gsr_sh_grad_from_views(n, _host.ptr(means3D), int(degree), len(chunk), ptrs, factor,
+                                                         _host.ptr(dst), _host.stream_ptr(dev)))
+            if c0:
+                out.add_(dst)
     return out

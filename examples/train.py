@@ -11,7 +11,7 @@ Targets: with --dataset <NeRF-synthetic dir> the train split (transforms_train.j
 train.py:323-334) is used; without it, targets are renders of a hidden seeded scene from orbiting cameras.
 
     python examples/train.py --iterations 200 --gaussians 20000
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train.py --views-per-step 8
+    python examples/train.py --gpus 8 --views-per-step 8        (launches its own 8 ranks; or under torch.distributed.run)
 """
 import argparse
 import importlib
@@ -19,10 +19,30 @@ import json
 import os
 import sys
 
-import numpy as np
-import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def _self_launch():
+    """`python examples/train.py --gpus N` (no WORLD_SIZE): start the N ranks before anything here touches the GPU."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    gpus = ap.parse_known_args()[0].gpus
+    if gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("gsr_launch", os.path.join(ROOT, "3dgs-native_amd", "launch.py"))
+        launch = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launch)
+        rc = launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], gpus)
+        sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 gsr = importlib.import_module("3dgs-native_amd")
 
 
@@ -40,6 +60,7 @@ def load_nerf(path, max_views):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); > 1 without WORLD_SIZE launches them itself")
     ap.add_argument("--dataset", default=None)
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--gaussians", type=int, default=5000)      # reference default (config.py:31)
@@ -59,6 +80,10 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not 1 <= args.views_per_step <= args.views:
+        raise SystemExit(f"--views-per-step {args.views_per_step} must be in 1..--views ({args.views}): a step draws its views without replacement")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = 0 if args.single_device else local
     torch.cuda.set_device(local)
@@ -125,7 +150,7 @@ def main():
         per_rank = -(-len(batch) // world)                                  # views per rank, rounded up
         if factored:
             if arena is None:
-                arena = torch.zeros(gsr.dist.SMALL_ARENA_FLOATS * n, device=dev)
+                arena = torch.zeros(gsr.dist.arena_size(n, small=True), device=dev)
             while len(payloads) < per_rank:                                 # ranks with a view less gather a zero payload
                 payloads.append(torch.zeros(3 * n + 4, device=dev))
             arena.mul_(world / len(batch))                                  # mean over the batch after the /world of the average
@@ -135,7 +160,7 @@ def main():
                                                                 scale=1.0 / len(batch))
         else:
             if arena is None:
-                arena = torch.zeros(gsr.dist.ARENA_FLOATS * n, device=dev)
+                arena = torch.zeros(gsr.dist.arena_size(n), device=dev)
             arena.mul_(1.0 / max(1, len(batch)))
             grads = gsr.dist.arena_views(arena, n)
         lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}

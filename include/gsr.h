@@ -17,12 +17,18 @@
  *   - All work is enqueued on `stream` (a hipStream_t).  Only gsr_forward_count waits on the device: for
  *     the number of (tile, Gaussian) pairs D, which sizes GsrBinning -- the reference's one unavoidable
  *     readback, forward.py:764.  It waits on an event behind the 4-byte copy only, so the depth sort it
- *     has already enqueued keeps running; the one piece of state the library keeps is that per-device
- *     pinned 4-byte slot and event (plus the optional profiling aid at the end of this header).
+ *     has already enqueued keeps running.  State the library keeps (host side, all of it behind mutexes, so host
+ *     threads may drive distinct buffers / streams concurrently): a pool of pinned 4-byte readback slots + events, one
+ *     leased per gsr_forward_count in flight; the count each geom_ws was last given (checked by gsr_forward_render ->
+ *     GSR_E_CAPACITY); the optional profiling aid at the end of this header.
  *   - Layouts are the reference's packed AoS: vec3 = 3 floats, vec4 = 4 floats, VEC6 = 6 floats
  *     (xx,xy,xz,yy,yz,zz; reference forward.py:186), images row-major [y][x].  Quaternions are
  *     (x,y,z,w) (forward.py:177).  Matrices are 16 floats row-major AS STORED by the reference's
  *     callers, used under the row-vector convention p' = p * M.
+ *   - Alignment: every array pointer handed to the library must be 16-byte aligned (hipMalloc and torch give 256).  The
+ *     kernels move vec4 / vec2 / SH rows as 16- and 8-byte accesses, so this matters for slices of a larger allocation: a
+ *     gradient arena [3N | 3N | 4N | N | 48N] must start each segment on a multiple of 4 floats (3dgs-native_amd/dist.py
+ *     arena_offsets pads it so).  Entry points check it and return GSR_E_ALIGN.
  *   - Tiles are 16x16 pixels (reference config.py:21-22).
  *   - Return value: GSR_OK or a negative GSR_E_* code; gsr_strerror() names it.
  */
@@ -48,7 +54,8 @@ enum {
     GSR_E_OVERFLOW = -3,  /* D > GSR_MAX_RENDERED (reference raises ValueError, forward.py:765) */
     GSR_E_WORKSPACE = -4, /* workspace null or smaller than *_workspace_bytes(...) */
     GSR_E_HIP = -5,       /* a HIP runtime call or kernel launch failed */
-    GSR_E_CAPACITY = -6   /* GsrBinning.D does not match the count returned by gsr_forward_count */
+    GSR_E_CAPACITY = -6,  /* GsrBinning.D is not the count gsr_forward_count returned for this geom_ws (or it was never counted) */
+    GSR_E_ALIGN = -7      /* an array pointer is not 16-byte aligned (see "Alignment" above) */
 };
 
 /* Inputs of wp_preprocess (reference forward.py:190-211). */
@@ -131,6 +138,10 @@ typedef struct GsrGrads {
 
 int gsr_abi_version(void);
 const char *gsr_strerror(int code);
+/* 0 for the product library.  Bit 0 (GSR_BUILD_ABLATE) marks the separate timing-ablation build (libgsr_hip_ablate.so,
+ * `make ablate`), the only build in which GSR_DEBUG bits 0-3 -- switches that skip work and give WRONG results -- exist. */
+#define GSR_BUILD_ABLATE 1
+int gsr_build_flags(void);
 
 /* Scratch sizes in bytes (host-side arithmetic only). */
 size_t gsr_geom_workspace_bytes(int64_t N);
@@ -269,7 +280,7 @@ int gsr_reset_opacities(int64_t N, float max_opacity, float *opacities, void *st
  * rotations (1,0,0,0) as stored, opacities 0.1, SH DC -0.007 and zeros above. */
 int gsr_init_gaussians(const GsrParams *out, float init_scale, void *stream);
 
-/* ---- profiling aid (the only process-wide state in the library; not thread-safe) ----------------
+/* ---- profiling aid (process-wide: every thread's sampled calls land in the one record) ----------------
  * With timing enabled every stage boundary of the three entry points records a hipEvent on the
  * caller's stream (about 3 us each, and kernels no longer dispatch back to back across a record: ~6 % of a
  * C3 step if every step is recorded, so bench.py samples one step in five); up to `max_steps` pairs are kept.

@@ -406,6 +406,72 @@ void gsro_render_backward_rows(int W, int H, int tile_y0, int tile_y1, const int
                 }
 }
 
+/* SECOND CHECKER for ill-conditioned (needle-like) splats -- not a restatement of any reference function.
+ * Every per-(pixel, entry) term is formed exactly as gsro_render_backward_rows forms it (same float32 expressions, same
+ * replay of alpha and T), but the per-Gaussian sums over pixels are kept in float64, so the result carries no
+ * accumulation-order rounding.  tests/test_gpu_fuzz.py uses it to tell two things apart that the plain comparison mixes:
+ * how far the reference's own serial float32 sum is from the exactly accumulated one, and how far the HIP kernel is. */
+void gsro_render_backward_rows_acc64(int W, int H, int tile_y0, int tile_y1, const int32_t *ranges,
+                                     const int32_t *point_list, const float *bg, const float *xy,
+                                     const float *conic_opacity, const float *colors, const float *final_Ts,
+                                     const int32_t *n_contrib, const float *dL_dpixels, double *dL_dmean2D,
+                                     double *dL_dconic2D, double *dL_dopacity, double *dL_dcolors)
+{
+    const int grid_x = (W + TILE_M - 1) / TILE_M;
+    for (int tile_x = 0; tile_x < grid_x; ++tile_x)
+        for (int tile_y = tile_y0; tile_y < tile_y1; ++tile_y)
+            for (int tid_x = 0; tid_x < TILE_M; ++tid_x)
+                for (int tid_y = 0; tid_y < TILE_N; ++tid_y) {
+                    int pix_x = tile_x * TILE_M + tid_x, pix_y = tile_y * TILE_N + tid_y;
+                    if (!(pix_x < W && pix_y < H)) continue;
+                    float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+                    int tile_id = tile_y * grid_x + tile_x;
+                    int range_start = ranges[2 * tile_id], range_end = ranges[2 * tile_id + 1];
+                    size_t px = (size_t)pix_y * W + pix_x;
+                    float T_final = final_Ts[px];
+                    int last_kept = imin(range_end, range_start + n_contrib[px]);
+                    float T = T_final;
+                    float accum_rec[3] = {0.0f, 0.0f, 0.0f};
+                    float last_alpha = 0.0f, last_color[3] = {0.0f, 0.0f, 0.0f};
+                    const float *dL_dpixel = dL_dpixels + 3 * px;
+                    float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+                    for (int i = last_kept - 1; i > range_start - 1; --i) {
+                        int gid = point_list[i];
+                        const float *pxy = xy + 2 * gid, *con_o = conic_opacity + 4 * gid, *color = colors + 3 * gid;
+                        float d_x = pxy[0] - pixf_x, d_y = pxy[1] - pixf_y;
+                        float power = -0.5f * (con_o[0] * d_x * d_x + con_o[2] * d_y * d_y) - con_o[1] * d_x * d_y;
+                        if (power > 0.0f) continue;
+                        float G = expf(power);
+                        float alpha = fminf_(0.99f, con_o[3] * G);
+                        if (alpha < (1.0f / 255.0f)) continue;
+                        T = T / (1.0f - alpha);
+                        float dchannel_dcolor = alpha * T;
+                        float tmp[3];
+                        for (int c = 0; c < 3; ++c) {
+                            accum_rec[c] = last_alpha * last_color[c] + (1.0f - last_alpha) * accum_rec[c];
+                            last_color[c] = color[c];
+                            tmp[c] = color[c] - accum_rec[c];
+                        }
+                        float dL_dalpha = dot3(tmp, dL_dpixel);
+                        for (int c = 0; c < 3; ++c) dL_dcolors[3 * gid + c] += (double)(dchannel_dcolor * dL_dpixel[c]);
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        float bg_dot_dpixel = dot3(bg, dL_dpixel);
+                        dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot_dpixel;
+                        float dL_dG = con_o[3] * dL_dalpha;
+                        float gdx = G * d_x, gdy = G * d_y;
+                        float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
+                        float dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
+                        dL_dmean2D[3 * gid] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                        dL_dmean2D[3 * gid + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                        dL_dconic2D[4 * gid] += (double)(-0.5f * gdx * d_x * dL_dG);
+                        dL_dconic2D[4 * gid + 1] += (double)(-0.5f * gdx * d_y * dL_dG);
+                        dL_dconic2D[4 * gid + 3] += (double)(-0.5f * gdy * d_y * dL_dG);
+                        dL_dopacity[gid] += (double)(G * dL_dalpha);
+                    }
+                }
+}
+
 /* backward.py:259-435 (compute_cov2d_backward_kernel).  dL_dconics (N,4); dL_dmeans (N,3) +=;
  * dL_dcov3Ds (N,6) written.  NOTE quirk Q1: uses T = W*J, cov2D = T^T Vrk^T T. */
 void gsro_cov2d_backward(int N, const float *means, const float *cov3Ds, const int32_t *radii, float h_x,

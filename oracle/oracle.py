@@ -36,7 +36,7 @@ def lib():
             build()
         _LIB = C.CDLL(path)
         for name in ("gsro_preprocess", "gsro_prefix_sum", "gsro_duplicate_with_keys", "gsro_sort_pairs",
-                     "gsro_identify_tile_ranges", "gsro_render_rows", "gsro_render_backward_rows",
+                     "gsro_identify_tile_ranges", "gsro_render_rows", "gsro_render_backward_rows", "gsro_render_backward_rows_acc64",
                      "gsro_cov2d_backward", "gsro_projection_backward", "gsro_sh_backward",
                      "gsro_cov3d_backward", "gsro_l1_pixel_grad", "gsro_adam_update"):
             getattr(_LIB, name).restype = None
@@ -143,8 +143,9 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
              scale_modifier=1.0, viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5,
              image_height=256, image_width=256, campos=None, radii=None, means2D=None,
              conic_opacity=None, rgb=None, clamped=None, cov3Ds=None, geom_buffer=None,
-             binning_buffer=None, img_buffer=None, degree=3, debug=False, tile_rows=None):
-    """Restates backward.py:955-1196 (backward_render :890, backward_preprocess :770)."""
+             binning_buffer=None, img_buffer=None, degree=3, debug=False, tile_rows=None, accumulate="f32"):
+    """Restates backward.py:955-1196 (backward_render :890, backward_preprocess :770).  accumulate="f64" is NOT the
+    reference: it swaps the blend backward for the float64-accumulating second checker (gsro_render_backward_rows_acc64)."""
     L = lib()
     H, W = int(image_height), int(image_width)
     focal_y = H / (2.0 * float(tan_fovy))                            # backward.py:1044-1045 (float64)
@@ -187,9 +188,18 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     dL_drot = np.zeros((N, 4), np.float32)
     gy = (H + TILE - 1) // TILE
     y0, y1 = (0, gy) if tile_rows is None else tile_rows
-    L.gsro_render_backward_rows(C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), _i(ranges), _i(point_list),
-                                _f(bg), _f(m2d), _f(con), _f(col), _f(final_Ts), _i(n_contrib), _f(dpix),
-                                _f(dL_dmean2D), _f(dL_dconic), _f(dL_dopacity), _f(dL_dcolor))
+    if accumulate == "f64":
+        # second checker (not a reference restatement): same float32 terms, per-Gaussian sums kept in float64, rounded once
+        acc = [np.zeros((N, 3)), np.zeros((N, 4)), np.zeros(N), np.zeros((N, 3))]
+        _d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        L.gsro_render_backward_rows_acc64(C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), _i(ranges), _i(point_list),
+                                          _f(bg), _f(m2d), _f(con), _f(col), _f(final_Ts), _i(n_contrib), _f(dpix),
+                                          _d(acc[0]), _d(acc[1]), _d(acc[2]), _d(acc[3]))
+        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor = [np.ascontiguousarray(a, dtype=np.float32) for a in acc]
+    else:
+        L.gsro_render_backward_rows(C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), _i(ranges), _i(point_list),
+                                    _f(bg), _f(m2d), _f(con), _f(col), _f(final_Ts), _i(n_contrib), _f(dpix),
+                                    _f(dL_dmean2D), _f(dL_dconic), _f(dL_dopacity), _f(dL_dcolor))
     dL_dcov3D = np.zeros((N, 6), np.float32)        # backward.py:812 (local)
     L.gsro_cov2d_backward(C.c_int(N), _f(means), _f(c3), _i(radii), C.c_float(focal_x), C.c_float(focal_y),
                           C.c_float(tan_fovx), C.c_float(tan_fovy), _f(view), _f(dL_dconic), _f(dL_dmean3D),

@@ -1,23 +1,24 @@
 """Shared comparison helpers for the GPU parity tests (HIP library vs CPU oracle).
 
-Tolerances (stated here, used by every test):
+Tolerances = SURVEY.md section 8(d)'s contract (stated here, used by every test, smoke() and bench.py):
   * integer / index outputs of the geometry and binning stages (radii, point_offsets, point_list,
     ranges) must be EXACT;
   * float per-Gaussian outputs (xy, depth, cov3D, conic, colour) within 1e-6 relative: both sides
     evaluate the same float32 expression tree without FMA contraction, with correctly rounded
     division and sqrt, so they are expected to be bit-identical;
-  * image / inverse depth / final_T: |d| <= 2e-5 on >= 99.9 % of pixels and <= 5e-3 on the rest (one flipped
-    alpha < 1/255 test moves T by up to T/255 = 3.9e-3: seed 1752 of the round-1 sweep, 2.8e-3 at one pixel).
-    The only arithmetic difference is exp(): v_exp_f32(x*log2e) on the GPU vs libm expf in the
-    oracle (relative error < 5e-7); the "rest" are pixels where that flips one of the discrete tests
-    alpha < 1/255 or T < 1e-4;
-  * n_contrib exact on >= 99.9 % of pixels;
-  * gradients: |d| <= 1e-4 * max|g| + 2e-3 * |g| element-wise on >= 99.9 % of the elements and
+  * image / inverse depth / final_T: |d| <= 2e-5 on >= 99.9 % of pixels and <= 1e-3 on the rest, EXCEPT at listed
+    threshold flips: at most max(2, 1e-5 * pixels) pixels may exceed 1e-3, and none 5e-3.  The only arithmetic difference
+    is exp(): v_exp_f32(x*log2e) on the GPU vs libm expf in the oracle (relative error < 5e-7); where that flips one of the
+    discrete tests alpha < 1/255 or T < 1e-4 at a pixel, T there moves by up to T/255 = 3.9e-3 (seed 1752 of the round-1
+    sweep: 2.8e-3 at ONE pixel).  The flips found are returned (and printed by the full-size tests);
+  * n_contrib exact on >= 99.9 % of pixels (the same flips);
+  * gradients: |d| <= 1e-4 * max|g| + 1e-3 * |g| element-wise on >= 99.9 % of the elements and
     <= 2e-2 * max|g| on the rest (float sums are re-associated: wave/tile reduction + atomics vs the
-    oracle's serial order); in an array of fewer than 4000 elements the components
-    of ONE Gaussian (up to 4) may sit in the loose band: one flipped alpha < 1/255 test in the replay, or float-atomic
-    order on an ill-conditioned splat, moves all components of that Gaussian's gradient (seeds 21 and 2673 of the round-1
-    sweeps: 1.1e-4 * max|g| in one run, 0.65e-4 in the next).
+    oracle's serial order; the rest are Gaussians downstream of a flipped test); in an array of fewer
+    than 4000 elements the components of ONE Gaussian (up to 4) may sit in the loose band: one flipped alpha < 1/255 test in
+    the replay, or float-atomic order on an ill-conditioned splat, moves all components of that Gaussian's gradient (seeds
+    21 and 2673 of the round-1 sweeps: 1.1e-4 * max|g| in one run, 0.65e-4 in the next).
+Every assert_* returns its measured margin so callers can print it (the full-size tests and bench.py do).
 """
 import numpy as np
 
@@ -43,7 +44,11 @@ def assert_close_rel(name, got, ref, rtol=1e-6, atol=1e-9):
     return float((got == ref).mean())
 
 
-def assert_image(name, got, ref, tight=2e-5, loose=5e-3, frac=0.999):
+IMG_TIGHT, IMG_LOOSE, IMG_FLIP_CAP, IMG_FLIP_FRAC = 2e-5, 1e-3, 5e-3, 1e-5
+
+
+def assert_image(name, got, ref, tight=IMG_TIGHT, loose=IMG_LOOSE, frac=0.999, flip_cap=IMG_FLIP_CAP):
+    """Returns (fraction within `tight`, max error, number of threshold-flip pixels beyond `loose`)."""
     got, ref = to_np(got), to_np(ref)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
     err = np.abs(got.astype(np.float64) - ref)
@@ -51,8 +56,11 @@ def assert_image(name, got, ref, tight=2e-5, loose=5e-3, frac=0.999):
         err = err.max(axis=2)
     ok = float((err <= tight).mean())
     assert ok >= frac, f"{name}: only {ok:.5f} of pixels within {tight} (max {err.max():.3e})"
-    assert err.max() <= loose, f"{name}: max error {err.max():.3e} > {loose}"
-    return ok, float(err.max())
+    flips = int((err > loose).sum())
+    allowed = max(2, int(IMG_FLIP_FRAC * err.size))
+    assert flips <= allowed, f"{name}: {flips} pixels beyond {loose} (allowed threshold flips: {allowed}); max {err.max():.3e}"
+    assert err.max() <= max(flip_cap, loose), f"{name}: max error {err.max():.3e} > {max(flip_cap, loose)}"
+    return ok, float(err.max()), flips
 
 
 def assert_counts(name, got, ref, frac=0.999):
@@ -62,19 +70,42 @@ def assert_counts(name, got, ref, frac=0.999):
     return ok
 
 
+GRAD_ABS, GRAD_REL, GRAD_REST = 1e-4, 1e-3, 2e-2
+
+
+def grad_margin(got, ref):
+    """(fraction of elements with |d| <= 1e-4 max|g| + 1e-3 |g|, max |d| / max|g|) -- the measured margin, no assertion."""
+    got, ref = to_np(got).astype(np.float64), to_np(ref).astype(np.float64)
+    m = np.abs(ref).max() if ref.size else 0.0
+    if m == 0.0:
+        return 1.0, float(np.abs(got).max()) if got.size else 0.0
+    err = np.abs(got - ref)
+    return float((err <= GRAD_ABS * m + GRAD_REL * np.abs(ref)).mean()), float(err.max() / m)
+
+
 def assert_grad(name, got, ref, frac=0.999):
     got, ref = to_np(got).astype(np.float64), to_np(ref).astype(np.float64)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
-    m = np.abs(ref).max()
+    m = np.abs(ref).max() if ref.size else 0.0
     if m == 0.0:
-        assert np.abs(got).max() == 0.0, f"{name}: reference is all zero, got max {np.abs(got).max():.3e}"
+        assert (np.abs(got).max() if got.size else 0.0) == 0.0, f"{name}: reference is all zero, got max {np.abs(got).max():.3e}"
         return 1.0, 0.0
-    err = np.abs(got - ref)
-    ok = float((err <= 1e-4 * m + 2e-3 * np.abs(ref)).mean())
+    ok, rel = grad_margin(got, ref)
     need = min(frac, 1.0 - 4.0 / ref.size)   # small arrays: one Gaussian's components (<= 4) may sit in the loose band too
-    assert ok >= need, f"{name}: only {ok:.5f} within tolerance (max err {err.max():.3e}, max|g| {m:.3e})"
-    assert err.max() <= 2e-2 * m, f"{name}: max err {err.max():.3e} vs max|g| {m:.3e}"
-    return ok, float(err.max() / m)
+    assert ok >= need, f"{name}: only {ok:.5f} within tolerance (max err {rel * m:.3e}, max|g| {m:.3e})"
+    assert rel <= GRAD_REST, f"{name}: max err {rel * m:.3e} vs max|g| {m:.3e}"
+    return ok, rel
+
+
+def format_report(report):
+    """One line per array: what was measured against the tolerance (printed by the full-size tests)."""
+    lines = []
+    for k, v in report.items():
+        if isinstance(v, tuple):
+            lines.append(f"  {k:18s} " + "  ".join(f"{x:.3e}" if isinstance(x, float) and x < 0.1 else (f"{x:.6f}" if isinstance(x, float) else str(x)) for x in v))
+        else:
+            lines.append(f"  {k:18s} {v:.6f}" if isinstance(v, float) else f"  {k:18s} {v}")
+    return "\n".join(lines)
 
 
 FWD_EXACT = ["radii", "point_offsets", "point_list", "ranges"]
@@ -93,7 +124,8 @@ def compare_forward(got, ref, report=None):
             report[k + "_biteq"] = eq
     r = {}
     r["image"] = assert_image("image", gi, ri)
-    r["depth"] = assert_image("inv_depth", gd, rd, tight=2e-5, loose=2e-2)
+    # inverse depth sums alpha*T/depth with depth >= 0.2: a flipped test moves it by up to 5x what it moves the image
+    r["depth"] = assert_image("inv_depth", gd, rd, tight=2e-5, loose=5e-3, flip_cap=2.5e-2)
     r["final_T"] = assert_image("final_Ts", gb["final_Ts"], rb["final_Ts"])
     r["n_contrib"] = assert_counts("n_contrib", gb["n_contrib"], rb["n_contrib"])
     if report is not None:

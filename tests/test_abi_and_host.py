@@ -216,3 +216,56 @@ def test_every_abi_symbol_is_documented_for_integrators():
     assert len(names) >= 28
     missing = [n for n in names if n not in doc]
     assert not missing, missing
+
+
+def test_product_build_has_no_ablation_switches(libpath):
+    """GSR_DEBUG bits 0-3 (skip atomics / one pixel per bucket / no SH fetch / no stores: wrong results, for timing only) exist
+    only in the separate `make ablate` build; the product library reports build flags 0 and its recipe has no -DGSR_ABLATE."""
+    _lib = sub("_lib")
+    assert _lib.lib().gsr_build_flags() == 0
+    mk = open(os.path.join(ROOT, PKG_NAME, "csrc", "Makefile")).read()
+    product_flags = re.search(r"^CXXFLAGS = (.*(?:\\\n.*)*)", mk, re.M).group(1)
+    assert "GSR_ABLATE" not in product_flags and "-DGSR_ABLATE" in mk
+    hdr = open(os.path.join(ROOT, PKG_NAME, "csrc", "gsr_internal.h")).read()
+    assert "#define GSR_ABL(flags, bit) false" in hdr and "#define GSR_DEBUG_ALLOWED (32 | 64)" in hdr
+    for f in ("blend_bwd_splat.hip", "preprocess.hip"):      # every use of the kernels' debug word goes through GSR_ABL
+        src = open(os.path.join(ROOT, PKG_NAME, "csrc", f)).read()
+        assert not re.search(r"\bdbg\s*&", src), f
+
+
+def test_alignment_and_capacity_are_checked_before_any_hip_call(libpath):
+    """include/gsr.h 'Alignment': array pointers must be 16-byte aligned -> GSR_E_ALIGN; gsr_forward_render refuses a geom
+    workspace that gsr_forward_count never counted -> GSR_E_CAPACITY.  Fake pointers: nothing is dereferenced."""
+    _lib = sub("_lib")
+    L = _lib.lib()
+    A = 0x10000         # any 16-byte aligned non-null value
+    scene = _lib.GsrScene(8, A, A, A + 4, A, A, 3, 1.0, 1)           # rotations off by 4 bytes
+    cam = _lib.GsrCamera()
+    cam.W, cam.H, cam.tan_fovx, cam.tan_fovy = 32, 32, 0.5, 0.5
+    geom = _lib.GsrGeom(A, A, A, A, A, A, A, A, A, None)
+    D = C.c_int64(0)
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), A, 1 << 30, C.byref(D), None) == _lib.GSR_E_ALIGN
+    scene.rotations = A
+    geom.conic_opacity = A + 8
+    assert L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), A, 1 << 30, C.byref(D), None) == _lib.GSR_E_ALIGN
+    geom.conic_opacity = A
+    binning, img = _lib.GsrBinning(100, A, A), _lib.GsrImage(A, A, A, A)
+    rc = L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), A, 1 << 30, A, 1 << 30, None)
+    assert rc == _lib.GSR_E_CAPACITY and "count" in _lib.strerror(rc)
+    grads = _lib.GsrGrads(A, A, A + 4, A, A, A, A, A, None)
+    rc = L.gsr_backward_geom(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(grads), A, 1 << 30, None)
+    assert rc == _lib.GSR_E_ALIGN
+    with pytest.raises(RuntimeError, match="aligned"):
+        _lib.check(_lib.GSR_E_ALIGN)
+
+
+def test_arena_offsets_are_16_byte_aligned():
+    d = sub("dist")
+    for n in (0, 1, 2, 3, 5, 7, 1000, 100003):
+        for small in (False, True):
+            o = d.arena_offsets(n, small)
+            assert all(x % 4 == 0 for x in o[:-1]) and o[-1] == d.arena_size(n, small)
+            sizes = [3 * n, 3 * n, 4 * n, n] + ([] if small else [48 * n])
+            assert all(o[k] + sizes[k] <= o[k + 1] for k in range(len(sizes)))
+            assert o[-1] - sum(sizes) <= 3 * (len(sizes) - 1)
+    assert d.arena_offsets(1000) == [0, 3000, 6000, 10000, 11000, 59000]      # N % 4 == 0: the plain 3N|3N|4N|N|48N layout

@@ -70,3 +70,37 @@ def test_world_size_2_gloo():
         assert shapes == {"dL_dmean3D": (1000, 3), "dL_dscale": (1000, 3), "dL_drot": (1000, 4), "dL_dopacity": (1000,),
                           "dL_dshs": (16000, 3)}
     assert res[0][4] == [0, 2, 4, 6] and res[1][4] == [1, 3, 5, 7]
+
+
+def _launch_mod():
+    import importlib
+    return importlib.import_module(f"{PKG_NAME}.launch")
+
+
+def test_self_launcher_two_ranks_gloo(tmp_path, capfd):
+    """The launcher behind `bench.py --gpus N` / `examples/train.py --gpus N`: two child ranks, gloo, CPU tensors."""
+    rc = _launch_mod().launch_ranks(os.path.join(ROOT, "tests", "dist_worker.py"), ["cpu", str(tmp_path)], 2, timeout=240)
+    assert rc == 0
+    out = capfd.readouterr().out
+    assert out.count('"rank0": "done"') == 1          # rank 0's stdout is relayed, rank 1's is dropped
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("arena", "small", "gathered"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert float(r0["arena"][0]) == 1.5 and float(r0["small"][-1]) == 1.5
+    assert r0["gathered"].shape == (2, 1504) and r0["gathered"][1, 0] == 1000.0
+
+
+def test_self_launcher_reports_failed_rank(tmp_path):
+    """A rank that dies ends the job with its exit code; the surviving rank is terminated, nothing is retried."""
+    import time
+    t0 = time.monotonic()
+    rc = _launch_mod().launch_ranks(os.path.join(ROOT, "tests", "dist_worker.py"), ["fail", str(tmp_path)], 2, timeout=240)
+    assert rc == 3
+    assert time.monotonic() - t0 < 50                 # rank 0 (sleeping 60 s) was stopped, not waited for
+
+
+def test_bench_launcher_branch_makes_no_gpu_call():
+    """bench.py decides to self-launch before torch is imported (the parent must not touch the GPU)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("launch_ranks(") < src.index("import torch\n")
+    assert "import torch" not in open(os.path.join(ROOT, PKG_NAME, "launch.py")).read()

@@ -45,3 +45,58 @@ def _case(scenes, cameras, seed):
 def test_random_configuration(oracle, cameras, scenes, seed):
     sc, cam, W, H, degree, train_convention, bg = _case(scenes, cameras, seed)
     _fwd_bwd(oracle, sc, cam, W, H, degree=degree, bg=bg, train_convention=train_convention)
+
+
+# ---- beyond 50:1: needle-like splats, where float32 accumulation order is the limit, for the oracle as for the kernel ----
+NEEDLE_CASES = int(os.environ.get("GSR_NEEDLE_CASES", "12"))
+
+
+def _needle_case(scenes, cameras, seed):
+    rng = np.random.default_rng(9000 + seed)
+    W, H = int(rng.integers(96, 260)), int(rng.integers(64, 200))
+    n = int(rng.choice([64, 300, 1024, 2500]))
+    sc = scenes.synthetic_scene(n, float(rng.choice([0.03, 0.12])), float(rng.uniform(0.3, 1.0)), seed=7000 + seed)
+    k = max(1, n // 8)
+    idx = rng.choice(n, size=k, replace=False)
+    ratio = rng.choice([100.0, 300.0, 1000.0], size=k).astype(np.float32)
+    long_axis = rng.uniform(0.5, 3.0, size=k).astype(np.float32)          # up to 3 scene units: splats over 1000 px long
+    sc["scales"][idx, 0] = long_axis
+    sc["scales"][idx, 1] = np.maximum(long_axis / ratio, np.float32(1e-3))
+    sc["scales"][idx, 2] = np.maximum(long_axis / ratio, np.float32(1e-3))
+    cam = lego_camera(cameras, frame=int(rng.integers(0, 8)), width=W, height=H)
+    return sc, cam, W, H
+
+
+@pytest.mark.parametrize("seed", range(NEEDLE_CASES))
+def test_needle_splats_against_both_checkers(oracle, cameras, scenes, seed):
+    """Anisotropy 100:1 .. 1000:1 with axes up to 3 scene units (the sweep above clamps these away).  Here the
+    conic is near-singular, `power` cancels from 1e4..1e6 down to a few units, and the per-Gaussian float32 sums lose digits
+    in ANY order -- the reference's serial one included.  So the kernel is held to the exactly accumulated answer (the
+    float64-accumulating checker, same float32 terms): it must meet the standard tolerance against it, or at least be as
+    close to it as the reference-order float32 sum is (factor 3), and its own run-to-run spread (float-atomic order) is
+    measured beside its error, not folded into the tolerance."""
+    import parity
+    from conftest import backward_kwargs, pkg, render_kwargs
+    gsr = pkg()
+    sc, cam, W, H = _needle_case(scenes, cameras, seed)
+    kw = render_kwargs(sc, cam, width=W, height=H)
+    got, ref = gsr.render_gaussians(**kw), oracle.render_gaussians(**kw)
+    parity.compare_forward(got, ref)                                   # the forward holds the standard contract even here
+    dpix = (np.random.default_rng(seed).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3)).astype(np.float32)
+    bkw = backward_kwargs(sc, cam, kw, ref[2], dpix)                  # both sides start from the oracle's forward buffers
+    g1, g2 = gsr.backward(**bkw), gsr.backward(**bkw)
+    o32, o64 = oracle.backward(**bkw), oracle.backward(**bkw, accumulate="f64")
+    rows = []
+    for k in ("dL_dcolor", "dL_dopacity", "dL_dmean2D", "dL_dconic", "dL_dmean3D", "dL_dscale", "dL_drot", "dL_dshs"):
+        ok_g, e_g = parity.grad_margin(g1[k], o64[k])                  # kernel vs exactly accumulated
+        ok_o, e_o = parity.grad_margin(o32[k], o64[k])                 # reference-order float32 sum vs exactly accumulated
+        _, spread = parity.grad_margin(g2[k], parity.to_np(g1[k]))     # kernel run to run
+        rows.append((k, ok_g, e_g, ok_o, e_o, spread))
+        need = min(0.999, 1.0 - 4.0 / max(1, parity.to_np(g1[k]).size))
+        standard = ok_g >= need and e_g <= parity.GRAD_REST
+        assert standard or (e_g <= 3.0 * e_o + 1e-6 and ok_g >= ok_o - 2e-3), \\
+            f"{k}: kernel {ok_g:.5f} inside / max {e_g:.2e}, float32 reference order {ok_o:.5f} / {e_o:.2e}, run-to-run {spread:.2e}"
+    if seed == 0 or os.environ.get("GSR_FUZZ_VERBOSE"):
+        print(f"\\nneedle case {seed} ({W}x{H}): array, kernel [frac inside, max err/max|g|] vs f64-accumulated; float32 reference order likewise; kernel run-to-run")
+        for r in rows:
+            print("  %-12s %.5f %.2e   %.5f %.2e   %.2e" % r)

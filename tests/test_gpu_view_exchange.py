@@ -73,8 +73,14 @@ def test_view_exchange_error_paths(scenes):
     good = torch.zeros(34, device="cuda")
     with pytest.raises(ValueError):
         gsr.dist.sh_gradients_from_views(means, [good[:-1]], 3)
-    with pytest.raises(RuntimeError):
-        gsr.dist.sh_gradients_from_views(means, [good] * 17, 3)     # more than GSR_MAX_VIEWS
+    with pytest.raises(ValueError):
+        gsr.dist.sh_gradients_from_views(means, [], 3)
+    # more rows than GSR_MAX_VIEWS (16): rebuilt in chunks of 16 and summed -- 20 copies of one payload, averaged, give it back
+    means_r = torch.as_tensor(np.random.default_rng(3).normal(0, 1, (10, 3)).astype(np.float32)).cuda()
+    pay = torch.as_tensor(np.random.default_rng(4).normal(0, 1, 34).astype(np.float32)).cuda()
+    one = gsr.dist.sh_gradients_from_views(means_r, [pay], 3, average=False)
+    many = gsr.dist.sh_gradients_from_views(means_r, [pay] * 20, 3, average=True)
+    np.testing.assert_allclose(many.cpu().numpy(), one.cpu().numpy(), rtol=2e-6, atol=1e-7)
     out = gsr.dist.sh_gradients_from_views(means, [good], 3)
     assert out.shape == (160, 3) and not out.any()
     with pytest.raises(ValueError):

@@ -134,3 +134,20 @@ def test_ssim_and_depth_loss_oracle_properties(oracle):
     assert oracle.depth_loss(d1, d2, np.zeros_like(d1)) == 0.0
     half = ones.copy(); half[:, 16:] = 0
     assert abs(oracle.depth_loss(d1, d2, half) - float((np.abs(d1 - d2) * half).mean())) < 1e-6
+
+
+def test_f64_accumulating_checker_agrees_with_the_restatement(oracle, cameras, scenes):
+    """oracle.backward(accumulate="f64") (the second checker of tests/test_gpu_fuzz.py's needle cases: same float32 terms,
+    per-Gaussian sums kept in float64) differs from the literal restatement only by float32 accumulation rounding: on a
+    well-conditioned scene the two agree to a few float32 ulps of the sum, on every gradient array."""
+    sc, cam = _scene(scenes, cameras, n=400, seed=9)
+    kw = render_kwargs(sc, cam, width=W, height=H, bg=(0.3, 0.2, 0.1))
+    img, dep, buf = oracle.render_gaussians(**kw)
+    dpix = np.random.default_rng(1).normal(0, 1, (H, W, 3)).astype(np.float32)
+    bkw = backward_kwargs(sc, cam, kw, buf, dpix)
+    a, b = oracle.backward(**bkw), oracle.backward(**bkw, accumulate="f64")
+    assert np.abs(a["dL_dcolor"]).max() > 0
+    for k in ("dL_dcolor", "dL_dopacity", "dL_dmean2D", "dL_dconic", "dL_dmean3D", "dL_dscale", "dL_drot", "dL_dshs"):
+        m = np.abs(b[k]).max()
+        assert np.abs(a[k].astype(np.float64) - b[k]).max() <= 2e-5 * m, k
+    assert not b["dL_dmean2D"][:, 2].any() and not b["dL_dconic"][:, 2].any()

@@ -63,6 +63,11 @@ def main():
                  "--no-cpu-baseline --no-stage-events` on MI355X; bytes per step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the "
                  "stage's kernels (gfx950 FETCH_SIZE reports half the bytes of wide reads: MI355X_MICROARCH.md, HBM); tools/summarize_pmc.py")
     d["_round"] = f"profiles/{label}_*"
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get("GSR_LIB", os.path.join(root, "3dgs-native_amd", "libgsr_hip.so"))
+    with open(lib, "rb") as f:      # bench.py quotes these bytes only for the build they were measured on
+        d["_build"] = hashlib.sha256(f.read()).hexdigest()[:16]
     d[config] = {k: int(v) for k, v in sorted(stage.items())}
     json.dump(d, open(path, "w"), indent=1)
     print(json.dumps(d[config]))
