@@ -81,9 +81,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher.  Nothing here has touched the GPU (torch is not even
         # imported yet); the ranks are fresh interpreters, each re-running this script with RANK/LOCAL_RANK/WORLD_SIZE set.
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("gsr_launch", os.path.join(ROOT, "3dgs-native_amd", "launch.py"))
-        launch = importlib.util.module_from_spec(spec)
+        from importlib import util as _ilu
+        spec = _ilu.spec_from_file_location("gsr_launch", os.path.join(ROOT, "3dgs-native_amd", "launch.py"))
+        launch = _ilu.module_from_spec(spec)
         spec.loader.exec_module(launch)
         rc = launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
         sys.exit(rc if rc >= 0 else 128 - rc)

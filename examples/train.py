@@ -29,9 +29,9 @@ def _self_launch():
     ap.add_argument("--gpus", type=int, default=1)
     gpus = ap.parse_known_args()[0].gpus
     if gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("gsr_launch", os.path.join(ROOT, "3dgs-native_amd", "launch.py"))
-        launch = importlib.util.module_from_spec(spec)
+        from importlib import util as _ilu
+        spec = _ilu.spec_from_file_location("gsr_launch", os.path.join(ROOT, "3dgs-native_amd", "launch.py"))
+        launch = _ilu.module_from_spec(spec)
         spec.loader.exec_module(launch)
         rc = launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], gpus)
         sys.exit(rc if rc >= 0 else 128 - rc)

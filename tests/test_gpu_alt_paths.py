@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("flags", [32, 64, 96])
 def test_parity_with_forced_paths(flags):
-    env = dict(os.environ, GSR_DEBUG=str(flags), GSR_FUZZ_CASES="48")
+    env = dict(os.environ, GSR_DEBUG=str(flags), GSR_FUZZ_CASES="48", GSR_NEEDLE_CASES="4")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
                         "-k", "not png and not c2_lego and not workspace and not full_size"],

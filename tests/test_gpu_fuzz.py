@@ -94,9 +94,10 @@ def test_needle_splats_against_both_checkers(oracle, cameras, scenes, seed):
         rows.append((k, ok_g, e_g, ok_o, e_o, spread))
         need = min(0.999, 1.0 - 4.0 / max(1, parity.to_np(g1[k]).size))
         standard = ok_g >= need and e_g <= parity.GRAD_REST
-        assert standard or (e_g <= 3.0 * e_o + 1e-6 and ok_g >= ok_o - 2e-3), \\
+        slack = max(2e-3, 4.0 / max(1, parity.to_np(g1[k]).size))       # small arrays: one Gaussian's components
+        assert standard or (e_g <= 3.0 * e_o + 1e-6 and ok_g >= ok_o - slack), \
             f"{k}: kernel {ok_g:.5f} inside / max {e_g:.2e}, float32 reference order {ok_o:.5f} / {e_o:.2e}, run-to-run {spread:.2e}"
     if seed == 0 or os.environ.get("GSR_FUZZ_VERBOSE"):
-        print(f"\\nneedle case {seed} ({W}x{H}): array, kernel [frac inside, max err/max|g|] vs f64-accumulated; float32 reference order likewise; kernel run-to-run")
+        print(f"\nneedle case {seed} ({W}x{H}): array, kernel [frac inside, max err/max|g|] vs f64-accumulated; float32 reference order likewise; kernel run-to-run")
         for r in rows:
             print("  %-12s %.5f %.2e   %.5f %.2e   %.2e" % r)
