@@ -30,7 +30,7 @@ class GsrGeom(C.Structure):
 
 
 class GsrBinning(C.Structure):
-    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp)]
+    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp), ("block_masks", vp)]
 
 
 class GsrImage(C.Structure):
@@ -111,7 +111,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gsr_abi_version() != 2:
+        if h.gsr_abi_version() != 3:
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -69,6 +69,7 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
         rgb = geom_buffer.get("rgb") if rgb is None else rgb
         clamped = geom_buffer.get("clamped_state") if clamped is None else clamped
     rec_tag = getattr(means2D, "_gsr_records", None)     # set by render_gaussians on its points_xy_image tensor
+    masks = getattr(point_list, "_gsr_block_masks", None)   # ... and on its point_list tensor
     radii = _host.to_dev(radii, i32, dev, (-1,))
     m2d = _host.to_dev(means2D, f32, dev, (-1, 2))
     con = _host.to_dev(conic_opacity, f32, dev, (-1, 4))
@@ -86,7 +87,10 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
                           float(scale_modifier), 1)
     geom = _lib.GsrGeom(_host.ptr(radii), None, None, _host.ptr(m2d), None, _host.ptr(c3), _host.ptr(col), _host.ptr(con),
                         _host.ptr(cl), _host.records_ptr(rec_tag, N, dev))
-    binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges))
+    if masks is not None and not (isinstance(masks, torch.Tensor) and masks.dtype == torch.uint8 and masks.device == dev
+                                  and masks.numel() == D and masks.is_contiguous()):
+        masks = None
+    binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks))
     img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
 
     from . import dist as _dist

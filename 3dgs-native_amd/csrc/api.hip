@@ -422,7 +422,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     // 5. point_list + ranges, 6. blend
     HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, id_shift, item_bytes, s));
     mark(st, 8, s);
-    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, s));
+    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, s));
     mark(st, 9, s);
     return GSR_OK;
 }
@@ -451,7 +451,7 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
         records = bw.rec;
     }
     mark(st, 11, s);
-    if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, bw.acc, s));
+    if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, binning->block_masks, bw.acc, s));
     mark(st, 12, s);
     if (payload) HIP_TRY(gsr_launch_view_payload(*scene, cam, *geom, bw.acc, payload, s));
     return GSR_OK;

@@ -115,14 +115,17 @@ __device__ __forceinline__ float power_ref_order(float ca, float cb, float cc, f
 
 constexpr int QCAP = 128; // ring of compacted entries (power of two, >= 2*64 - 1)
 
-template <int BW, int BH>
+// USE_MASKS: the per-block hit masks the forward wrote (GsrBinning.block_masks) replace the compaction's own test.  They are
+// per 8x4 block; an 8x8 block ORs the bits of its two halves, a 4x4 block keeps its own (finer) test.
+template <int BW, int BH, bool USE_MASKS>
 __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
                                                                   const int32_t *__restrict__ ranges,
                                                                   const int32_t *__restrict__ point_list,
                                                                   const BlendRec *__restrict__ rec,
                                                                   const float *__restrict__ final_T,
                                                                   const int32_t *__restrict__ n_contrib,
-                                                                  const float *__restrict__ dL_dpixels, GradRec *__restrict__ acc, int dbg)
+                                                                  const float *__restrict__ dL_dpixels,
+                                                                  const uint8_t *__restrict__ block_masks, GradRec *__restrict__ acc, int dbg)
 {
     constexpr int NPIX = BW * BH;            // pixels of the block this wave owns
     constexpr int PER_TILE = 256 / NPIX;     // blocks per 16x16 tile
@@ -164,6 +167,8 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const float fx0 = (float)bx0, fy0 = (float)by0;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // mask bit k <-> 8x4 block k of the tile: x half k & 1, row band k >> 1
+    const int mask_shift = BH == 4 ? sub : ((sub >> 1) * 4 + (sub & 1)), mask_bits = BH == 4 ? 1 : 5;
     __syncthreads();
 
     int cursor = hi_all; // next list index (exclusive) to pull candidates from, moving towards `start`
@@ -175,7 +180,15 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const int idx = cursor - 1 - lane;
             bool hit = false;
             int id = 0;
-            if (idx >= lo) {
+            if (USE_MASKS) {
+                // the forward already tested every staged entry against the tile's eight 8x4 blocks (blend_fwd.hip): one byte
+                // per entry, read coalesced, instead of two 16-byte gathers and the convex test per candidate
+                if (idx >= lo) {
+                    id = point_list[idx];
+                    const int mv = (int)block_masks[idx];
+                    hit = ((mv >> mask_shift) & mask_bits) != 0;
+                }
+            } else if (idx >= lo) {
                 id = point_list[idx];
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
                 float4 a = rp[0], b = rp[1];
@@ -306,18 +319,19 @@ int gsr_bwd_block = 32;
 int gsr_debug_flags = 0; // see gsr_internal.h
 
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
-                                           const GsrImage &img, const float *dL_dpixels, GradRec *acc, hipStream_t s)
+                                           const GsrImage &img, const float *dL_dpixels, const uint8_t *block_masks, GradRec *acc,
+                                           hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-#define LAUNCH(BW, BH)                                                                                                        \
-    hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH>), dim3(tiles * (256 / ((BW) * (BH)))), dim3(64), 0, s, cam.W, cam.H,  \
+#define LAUNCH(BW, BH, M)                                                                                                     \
+    hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH, M>), dim3(tiles * (256 / ((BW) * (BH)))), dim3(64), 0, s, cam.W, cam.H, \
                        cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib,      \
-                       dL_dpixels, acc, gsr_debug_flags)
+                       dL_dpixels, block_masks, acc, gsr_debug_flags)
     switch (gsr_bwd_block) { // pixels per wave: GSR_BWD_BLOCK = 32 (8x4, default: measured best at C3), 64 (8x8), 16 (4x4)
-    case 16: LAUNCH(4, 4); break;
-    case 64: LAUNCH(8, 8); break;
-    default: LAUNCH(8, 4); break;
+    case 16: LAUNCH(4, 4, false); break;
+    case 64: if (block_masks) LAUNCH(8, 8, true); else LAUNCH(8, 8, false); break;
+    default: if (block_masks) LAUNCH(8, 4, true); else LAUNCH(8, 4, false); break;
     }
 #undef LAUNCH
     return hipGetLastError();

@@ -1,24 +1,45 @@
 // blend_fwd.hip -- per-tile front-to-back alpha blending for gfx950.
 //
-// What the reference's wp_render_gaussians does per pixel (forward.py:385-515), restructured for
-// CDNA4: one 256-thread workgroup per 16x16 tile, each of its four waves owning one 8x8 pixel block.
-// The tile's sorted list is staged through LDS in batches of 256 entries, each entry gathered ONCE per
-// tile as a single 64-byte record (the reference gathers four arrays per pixel per entry).  While
-// staging, the thread that fetched an entry also tests it against the four 8x8 blocks (exact convex
-// minimum of the conic over the block rectangle vs ln(255 o), conservative) and stores a 4-bit hit
-// mask; a wave then skips, with one scalar test, every entry that cannot reach alpha >= 1/255 inside
-// its block -- most of a tile's list.  Live entries are read as LDS broadcasts.  A wave stops when its
-// 64 pixels are saturated (ballot), the tile when all four are (__syncthreads_and).
+// What the reference's wp_render_gaussians does per pixel (forward.py:385-515), restructured for CDNA4:
+// one 512-thread workgroup per 16x16 tile; each of its eight waves owns one 8x4 pixel block and blends TWO list entries
+// per wave instruction: lanes 0-31 hold the block's 32 pixels against entry A, lanes 32-63 the same pixels against the next
+// live entry B.  The tile's sorted list is staged through LDS in batches of 512 entries, each entry gathered ONCE per tile
+// as a single 64-byte record (the reference gathers four arrays per pixel per entry).  While staging, the thread that
+// fetched an entry tests it against the eight 8x4 blocks (exact convex minimum of the conic over the block rectangle vs
+// ln(255 o), conservative, behind an axis-aligned bounding-box pre-test) and stores an 8-bit hit mask; a wave then turns
+// the masks of a batch into its own compact list of live entries (ballot + mbcnt, indices in LDS) and walks that list two
+// entries at a time, so entries that cannot reach alpha >= 1/255 inside its block -- most of a tile's list -- cost it
+// nothing, and the walk needs no scalar bit loop.  The masks are also written out (GsrBinning.block_masks) so the
+// backward's per-block compaction reads one byte per entry instead of re-deriving the test from the records.
 //
-// Float operations are in the reference's order (no contraction) so the discrete tests (power > 0,
-// alpha < 1/255, T < 1e-4) agree with the CPU oracle except where exp() itself rounds differently:
-// exp is v_exp_f32(power * log2 e), relative error < 5e-7 for power in [-5.6, 0].  `n_contrib` is the
-// 1-based LIST position of the last contributing entry, so skipping dead entries does not change it.
+// The two halves exchange (1 - alpha) with one v_permlane32_swap, so every lane follows the exact sequential transmittance
+// chain T -> T(1-aA) -> T(1-aA)(1-aB) in the reference's operation order: the discrete tests (power > 0, alpha < 1/255,
+// T < 1e-4) and therefore final_T and n_contrib agree with the CPU oracle except where exp() itself rounds differently
+// (exp is v_exp_f32(power * log2 e), relative error < 5e-7 for power in [-5.6, 0]).  A pair in which some pixel would
+// saturate takes a slower, fully masked path; all others run branch-free.  Colour is accumulated per half (the A chain and
+// the B chain) and added at the end: a re-association of the reference's sum, far inside the image tolerance.
+// `n_contrib` is the 1-based LIST position of the last contributing entry, so skipping dead entries does not change it.
 #include "gsr_internal.h"
+
+// GSR_TIMELINE (diagnostic build only, never the product): per-phase shader-cycle totals over all waves
+#ifdef GSR_TIMELINE
+constexpr int TL_MAX_WAVES = 1 << 17;
+__device__ unsigned long long g_fwd_wave[TL_MAX_WAVES][8]; // one row per wave, plain stores (atomics would clog the memory pipe)
+#define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
+#define TL_COUNT(k, v) tl_acc[k] += (v);
+#define TL_FLUSH if (lane == 0) { const int tw = (blockIdx.x * 8 + wv) & (TL_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_fwd_wave[tw][q] = tl_acc[q]; }
+#else
+#define TL_DECL
+#define TL(k)
+#define TL_COUNT(k, v)
+#define TL_FLUSH
+#endif
 
 namespace {
 
-constexpr int BATCH = 256;
+constexpr int BATCH = 512;
+constexpr int NWAVES = 8;
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -30,10 +51,11 @@ __device__ __forceinline__ float edge_min_q(float qa, float qb, float qc, float 
     v = fminf(vhi, fmaxf(vlo, v));
     return 0.5f * (qa * u * u + qc * v * v) + qb * u * v;
 }
-// Can alpha reach 1/255 anywhere in pixels [x0,x0+7] x [y0,y0+7]?  Conservative (small slack).
+// Can alpha reach 1/255 anywhere in pixels [x0,x0+7] x [y0,y0+3]?  Conservative (small slack).  The same test, with the same
+// slack, is what the backward's own compaction applies when it has no masks (blend_bwd_splat.hip).
 __device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float lim, float x0, float y0)
 {
-    const float dxl = gx - (x0 + 7.0f), dxh = gx - x0, dyl = gy - (y0 + 7.0f), dyh = gy - y0;
+    const float dxl = gx - (x0 + 7.0f), dxh = gx - x0, dyl = gy - (y0 + 3.0f), dyh = gy - y0;
     float qmin;
     if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) qmin = 0.0f;
     else {
@@ -45,51 +67,85 @@ __device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, floa
     return qmin <= lim;
 }
 
-__global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
+// both halves of the wave receive (value held by lanes 0-31, value held by lanes 32-63) of the same pixel
+__device__ __forceinline__ void halves(float v, float &lo, float &hi)
+{
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); // r[0] = {v.lo, v.lo}, r[1] = {v.hi, v.hi}
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
+// LDS image of one staged entry: 48 bytes = {x, y, -a/2, -b | -c/2, opacity, r, g | b, 1/depth, -, -}.  The conic is stored as
+// (-a/2, -b, -c/2): scaling by a power of two and negation commute with float rounding, so
+//     power = (-a/2 dx) dx + (-c/2 dy) dy + (-b dx) dy
+// is bit for bit the reference's -0.5 (a dx dx + c dy dy) - b dx dy (forward.py:477-479) with one multiply less.
+// A 48-byte stride keeps the staging threads' 16-byte stores free of bank conflicts (12 i mod 32 over 8 lanes hits 8 distinct
+// 4-bank groups) and lets the blend loop address all three pieces of a record from ONE byte offset, which is what the waves'
+// compacted lists hold.
+constexpr int REC_BYTES = 48;
+constexpr int LIST_PAD = 8; // sentinel offsets behind a wave's list: the pair loop reads up to three pairs ahead without bounds tests
+
+struct PairRec {
+    float4 a, b;
+    float2 c;
+};
+
+__global__ __launch_bounds__(512, 6) void blend_forward_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
                                                             const int32_t *__restrict__ ranges,
                                                             const int32_t *__restrict__ point_list,
                                                             const BlendRec *__restrict__ rec, float *__restrict__ image,
                                                             float *__restrict__ inv_depth, float *__restrict__ final_T,
-                                                            int32_t *__restrict__ n_contrib)
+                                                            int32_t *__restrict__ n_contrib, uint8_t *__restrict__ block_masks)
 {
-    __shared__ float4 s_a[BATCH]; // xy.x xy.y con.a con.b
-    __shared__ float4 s_b[BATCH]; // con.c opacity r g
-    __shared__ float2 s_c[BATCH]; // b 1/depth
-    __shared__ int s_mask[BATCH]; // bit w: entry may touch block w
+    __shared__ __attribute__((aligned(16))) unsigned char s_rec[(BATCH + 1) * REC_BYTES]; // + one sentinel record (opacity 0: never valid)
+    __shared__ uint8_t s_mask[BATCH];                      // bit k: entry may touch 8x4 block k (k & 1 = x half, k >> 1 = row band)
+    __shared__ uint16_t s_list[NWAVES][BATCH + LIST_PAD];  // per wave: byte offsets (into s_rec) of its live entries, in list order
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, p = lane & 31;
     const int tile = blockIdx.x;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const int pix_x = tile_x * 16 + (wv & 1) * 8 + (lane & 7);
-    const int pix_y = tile_y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    const int pix_x = tile_x * 16 + (wv & 1) * 8 + (p & 7);
+    const int pix_y = tile_y * 16 + (wv >> 1) * 4 + (p >> 3);
     float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
     asm volatile("" : "+v"(pixf_x), "+v"(pixf_y)); // keep the converted coordinates in registers (hipcc re-converts them per entry otherwise)
     const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
-    const int mybit = 1 << wv;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
     const int start = range.x, end = range.y;
 
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f;
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f; // T: the pixel's transmittance (same in both halves); c*: this half's chain
     int last = 0;
     bool done = !(pix_x < W && pix_y < H);
+    if (tid < 3) reinterpret_cast<float4 *>(s_rec + BATCH * REC_BYTES)[tid] = make_float4(0.f, 0.f, 0.f, 0.f); // the sentinel
 
+    TL_DECL
     // software pipeline: the gather of batch k+1 (id, then its 64-byte record) is in flight while batch k is blended
     int nid = (start + tid < end) ? point_list[start + tid] : -1;
-    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, ncd = na;
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+    float2 ncd = make_float2(0.f, 0.f);
     if (nid >= 0) {
         const float4 *rp = reinterpret_cast<const float4 *>(rec + nid);
-        na = rp[0]; nb = rp[1]; ncd = rp[2];
+        na = rp[0]; nb = rp[1];
+        ncd = *reinterpret_cast<const float2 *>(rp + 2);
     }
     for (int base = start; base < end; base += BATCH) {
         if (__syncthreads_and(done)) break; // whole tile saturated (also fences LDS reuse)
+        TL(0) // top barrier (first time: launch -> here)
 
         const int cnt = min(BATCH, end - base);
+#ifdef GSR_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TL(1) // waiting for the gathered records
+#endif
         if (tid < cnt) {
-            const float4 a = na, b = nb, c = ncd;
-            s_a[tid] = a;
-            s_b[tid] = b;
-            s_c[tid] = make_float2(c.x, c.y);
+            const float4 a = na, b = nb;
+            float4 *dst = reinterpret_cast<float4 *>(s_rec + tid * REC_BYTES);
+            dst[0] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
+            dst[1] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
+            *reinterpret_cast<float2 *>(dst + 2) = ncd;
             int m = 0;
             if (b.y * 255.0f >= 1.0f) {
                 const float lim = __builtin_amdgcn_logf(b.y * 255.0f) * 0.6931471805599453f * 1.0001f + 1e-3f; // ln via v_log_f32, argument >= 1
@@ -100,78 +156,126 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
                 const float kdet = 2.0f * lim * fast_rcp(det);
                 const float hx = __builtin_amdgcn_sqrtf(kdet * b.x) * 1.001f + 0.05f, hy = __builtin_amdgcn_sqrtf(kdet * a.z) * 1.001f + 0.05f;
                 const float lx = a.x - hx - tx0, rx = a.x + hx - tx0, ly = a.y - hy - ty0, ry = a.y + hy - ty0; // box relative to the tile origin
-                const bool xin[2] = {boxless || (lx <= 7.0f && rx >= 0.0f), boxless || (lx <= 15.0f && rx >= 8.0f)};
-                const bool yin[2] = {boxless || (ly <= 7.0f && ry >= 0.0f), boxless || (ly <= 15.0f && ry >= 8.0f)};
+                // candidate blocks = those the box overlaps; the exact test runs once per candidate (most splats have one to four), the
+                // loop's trip count being the largest candidate count among the wave's 64 entries
+                int cand = 0;
+                {
+                    const int xm = (boxless || (lx <= 7.0f && rx >= 0.0f) ? 0x55 : 0) | (boxless || (lx <= 15.0f && rx >= 8.0f) ? 0xAA : 0);
+                    int ym = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (xin[k & 1] && yin[k >> 1] &&
-                        block_may_hit(a.x, a.y, a.z, a.w, b.x, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 8))) m |= 1 << k;
+                    for (int r = 0; r < 4; ++r)
+                        if (boxless || (ly <= (float)(4 * r + 3) && ry >= (float)(4 * r))) ym |= 3 << (2 * r);
+                    cand = xm & ym;
+                }
+                while (cand) {
+                    const int k = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    if (block_may_hit(a.x, a.y, a.z, a.w, b.x, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 4))) m |= 1 << k;
+                }
             }
-            s_mask[tid] = m;
+            s_mask[tid] = (uint8_t)m;
+            if (block_masks) block_masks[base + tid] = (uint8_t)m; // for the backward's compaction: one byte per staged entry
         }
+        TL(2) // staging: LDS image + masks
         // issue the next batch's gather now; it completes under the blend loop below
         {
             const int nidx = base + BATCH + tid;
             nid = (nidx < end) ? point_list[nidx] : -1;
             if (nid >= 0) {
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + nid);
-                na = rp[0]; nb = rp[1]; ncd = rp[2];
+                na = rp[0]; nb = rp[1];
+                ncd = *reinterpret_cast<const float2 *>(rp + 2);
             }
         }
         __syncthreads();
+        TL(3) // staging barrier
 
         if (__all(done)) continue; // this wave has nothing left; keep serving the barriers
 
-        // each wave walks only the entries whose mask has its bit: 64 mask words -> one ballot -> scalar bit loop.
-        // Two register sets alternate so the LDS broadcast reads of the next live entry are in flight while the
-        // current one is blended (no register shuffling); saturation of the whole wave is re-checked once per
-        // 64-entry group, not per entry.
-#define GSR_BLEND(A, B, C, J)                                                                                                  \
-    {                                                                                                                         \
-        const float dx = A.x - pixf_x, dy = A.y - pixf_y;                                                                     \
-        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                                          \
-        const float alpha = fminf(0.99f, B.y * fast_exp(power));                                                              \
-        const float test_T = T * (1.0f - alpha);                                                                              \
-        const bool live = !done && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));                                             \
-        const bool sat = live && (test_T < 0.0001f);                                                                          \
-        done = done || sat;                                                                                                   \
-        if (live && !sat) {                                                                                                   \
-            cr += B.z * alpha * T;                                                                                            \
-            cg += B.w * alpha * T;                                                                                            \
-            cb += C.x * alpha * T;                                                                                            \
-            cd += C.y * alpha * T;                                                                                            \
-            T = test_T;                                                                                                       \
-            last = base - start + (J) + 1;                                                                                    \
-        }                                                                                                                     \
-    }
+        // this wave's live entries of the batch, compacted in list order (LDS operations of one wave execute in order, so the
+        // list can be read back without a barrier); sentinels behind it
+        int n = 0;
         for (int g = 0; g < cnt; g += 64) {
-            const int mv = (g + lane < cnt) ? s_mask[g + lane] : 0;
-            unsigned long long bits = __ballot((mv & mybit) != 0);
-            if (!bits) continue;
-            int j0 = g + __builtin_ctzll(bits);
-            bits &= bits - 1;
-            float4 a0 = s_a[j0], b0 = s_b[j0];
-            float2 c0 = s_c[j0];
-            for (;;) {
-                int j1 = j0;
-                const bool more1 = bits != 0;
-                if (more1) { j1 = g + __builtin_ctzll(bits); bits &= bits - 1; }
-                const float4 a1 = s_a[j1], b1 = s_b[j1];
-                const float2 c1 = s_c[j1];
-                GSR_BLEND(a0, b0, c0, j0);
-                if (!more1) break;
-                const bool more0 = bits != 0;
-                if (more0) { j0 = g + __builtin_ctzll(bits); bits &= bits - 1; }
-                a0 = s_a[j0]; b0 = s_b[j0]; c0 = s_c[j0];
-                GSR_BLEND(a1, b1, c1, j1);
-                if (!more0) break;
-            }
-            if (__all(done)) break; // the wave's 64 pixels are saturated: nothing later in the list can contribute
+            const int mv = (g + lane < cnt) ? (int)s_mask[g + lane] : 0;
+            const bool hit = ((mv >> wv) & 1) != 0;
+            const unsigned long long bits = __ballot(hit);
+            if (hit) s_list[wv][n + __popcll(bits & lt_mask)] = (uint16_t)((g + lane) * REC_BYTES);
+            n += __popcll(bits);
         }
-#undef GSR_BLEND
+        if (lane < LIST_PAD) s_list[wv][n + lane] = (uint16_t)(BATCH * REC_BYTES);
+        TL(4) // list build
+        TL_COUNT(7, (unsigned long long)((n + 1) / 2))
+
+        // two entries per step: lanes 0-31 take list[k], lanes 32-63 list[k+1].  Two-deep software pipeline: the offsets of
+        // pair k+2 and the records of pair k+1 are in flight while pair k is blended.
+        const uint16_t *lp = &s_list[wv][half];
+        auto fetch = [&](int off) {
+            PairRec r;
+            const float4 *q = reinterpret_cast<const float4 *>(s_rec + off);
+            r.a = q[0]; r.b = q[1];
+            r.c = *reinterpret_cast<const float2 *>(q + 2);
+            return r;
+        };
+        int off_cur = lp[0], off_nxt = lp[2];
+        PairRec cur = fetch(off_cur);
+        int last_off = -1;
+        for (int k = 0; k < n; k += 2) {
+            const PairRec nxt = fetch(off_nxt);
+            const int off_n2 = lp[4];
+            lp += 2;
+            const float dx = cur.a.x - pixf_x, dy = cur.a.y - pixf_y;
+            const float power = (cur.a.z * dx * dx + cur.b.x * dy * dy) + cur.a.w * dx * dy; // see REC_BYTES: the reference's value, bit for bit
+            const float alpha = fminf(0.99f, cur.b.y * fast_exp(power));
+            const bool valid = !done && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
+            const float a_eff = valid ? alpha : 0.0f;
+            float omA, omB;
+            halves(1.0f - a_eff, omA, omB);      // (1 - alpha) of entry A and of entry B for this pixel; 1 where the entry does nothing
+            const float T1 = T * omA, T2 = T1 * omB; // the reference's test_T after A, after B (forward.py:486)
+            if (__builtin_amdgcn_ballot_w64(T2 < 0.0001f && !done) != 0ull) {
+                // some pixel saturates inside this pair: the exact sequential logic, lane by lane (forward.py:486-489: an entry that
+                // would push T below 1e-4 is not applied and ends the pixel)
+                const bool vA = omA < 1.0f, vB = omB < 1.0f;           // entry valid for this pixel (alpha >= 1/255 > 0)
+                const bool satA = vA && (T1 < 0.0001f);
+                const bool applyA = vA && !satA;
+                const float Ta = applyA ? T1 : T;
+                const float Tb = Ta * omB;
+                const bool satB = vB && !satA && (Tb < 0.0001f);
+                const bool applyB = vB && !satA && !satB;
+                const bool mine = half ? applyB : applyA;
+                const float w = mine ? alpha * (half ? Ta : T) : 0.0f;
+                cr = __builtin_fmaf(cur.b.z, w, cr); cg = __builtin_fmaf(cur.b.w, w, cg);
+                cb = __builtin_fmaf(cur.c.x, w, cb); cd = __builtin_fmaf(cur.c.y, w, cd);
+                if (mine) last_off = off_cur;
+                T = applyB ? Tb : Ta;
+                done = done || satA || satB;
+                if (__all(done)) break; // the wave's 32 pixels are saturated: nothing later in the list can contribute
+            } else {
+                const float w = a_eff * (half ? T1 : T);
+                cr = __builtin_fmaf(cur.b.z, w, cr); cg = __builtin_fmaf(cur.b.w, w, cg);
+                cb = __builtin_fmaf(cur.c.x, w, cb); cd = __builtin_fmaf(cur.c.y, w, cd);
+                if (valid) last_off = off_cur;
+                T = T2;
+            }
+            cur = nxt;
+            off_cur = off_nxt;
+            off_nxt = off_n2;
+        }
+        // n_contrib = 1-based list position of the last contributing entry: offset / 48 by multiply-shift (exact below 2^16)
+        if (last_off >= 0) last = base - start + (int)(((unsigned)last_off * 43691u) >> 21) + 1;
+        TL(5) // pair loop
     }
 
-    if (pix_x < W && pix_y < H) {
+    // add the two chains; lanes 0-31 write the block's pixels
+    {
+        float lo, hi;
+        halves(cr, lo, hi); cr = lo + hi;
+        halves(cg, lo, hi); cg = lo + hi;
+        halves(cb, lo, hi); cb = lo + hi;
+        halves(cd, lo, hi); cd = lo + hi;
+        halves(__int_as_float(last), lo, hi);
+        last = max(__float_as_int(lo), __float_as_int(hi));
+    }
+    if (half == 0 && pix_x < W && pix_y < H) {
         const size_t px = (size_t)pix_y * W + pix_x;
         final_T[px] = T;
         n_contrib[px] = last;
@@ -180,16 +284,26 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         image[3 * px + 2] = cb + T * bg2;
         inv_depth[px] = cd;
     }
+    TL(6)
+    TL_FLUSH
 }
 
 } // namespace
 
+#ifdef GSR_TIMELINE
+extern "C" int gsr_debug_fwd_phases(unsigned long long *out /* [waves][8] */, int waves)
+{
+    if (waves > TL_MAX_WAVES) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_wave), sizeof(unsigned long long) * 8 * (size_t)waves) == hipSuccess ? 0 : -1;
+}
+#endif
+
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
-                                    const GsrImage &img, hipStream_t s)
+                                    const GsrImage &img, uint8_t *block_masks, hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
-                       ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib);
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(512), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
+                       ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks);
     return hipGetLastError();
 }

@@ -75,7 +75,7 @@ hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *
 hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift,
                              int item_bytes, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
-                                    const BlendRec *rec, const GsrImage &img, hipStream_t s);
+                                    const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */, hipStream_t s);
 
 // backward
 struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (atomics target)
@@ -84,7 +84,7 @@ struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (
 hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s);
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                            const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
-                                           GradRec *acc, hipStream_t s);
+                                           const uint8_t *block_masks /* optional: the forward's */, GradRec *acc, hipStream_t s);
 hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc,
                                     const GsrGrads &gr, hipStream_t s);
 

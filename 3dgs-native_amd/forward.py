@@ -57,7 +57,8 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         if debug:
             print(f"gsr: {W}x{H}, N={N}, D={D}, SH degree {degree}")
         point_list = e((D,), i32)
-        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges))
+        block_masks = e((D,), torch.uint8)     # per-entry 8x4-block hit masks: written by the forward blend, read by backward()
+        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks))
         bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
         _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
                                         _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
@@ -66,6 +67,9 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     # and is honoured only while no later forward has overwritten that workspace.
     if N > 0:
         xy._gsr_records = _host.tag_records(gws, N)
+        # likewise the block masks ride on the point_list tensor (their own allocation, alive as long as it is): a caller
+        # that hands backward() this very tensor gets the mask-driven compaction, anyone else the self-contained one
+        point_list._gsr_block_masks = block_masks
     return image, depth_image, {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
         "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,

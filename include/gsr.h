@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 #define GSR_TILE 16
 #define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
 #define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
@@ -107,6 +107,11 @@ typedef struct GsrBinning {
     int64_t D;           /* number of (tile, Gaussian) pairs, from gsr_forward_count */
     int32_t *point_list; /* [D] Gaussian ids sorted by (tile, depth bits, id) */
     int32_t *ranges;     /* [tiles*2] (start,end) per tile, (0,0) for untouched tiles */
+    uint8_t *block_masks; /* optional [D], not part of the reference's dict: bit k of byte i = list entry i may reach
+                             alpha >= 1/255 inside 8x4-pixel block k of its tile (k & 1 = x half, k >> 1 = 4-row band).
+                             gsr_forward_render writes it (entries up to each tile's saturation point) when not NULL;
+                             gsr_backward, given the SAME array back unmodified, compacts each block's list from these
+                             bytes instead of re-deriving the test from the records.  NULL on either side is fine. */
 } GsrBinning;
 
 /* Per-pixel outputs: image, inverse-depth image, dict entries final_Ts / n_contrib. */

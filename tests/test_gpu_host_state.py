@@ -50,7 +50,7 @@ def test_forward_render_refuses_a_wrong_count(cameras, scenes):
     bws = torch.empty(L.gsr_binning_workspace_bytes(n, D + 64, W, H), dtype=torch.uint8, device=dev)
 
     def render(d, ws):
-        b = _lib.GsrBinning(d, _host.ptr(point_list), _host.ptr(ranges))
+        b = _lib.GsrBinning(d, _host.ptr(point_list), _host.ptr(ranges), None)
         return L.gsr_forward_render(C.byref(scene), C.byref(cs), C.byref(geom), C.byref(b), C.byref(image), _host.ptr(ws), ws.numel(),
                                     _host.ptr(bws), bws.numel(), stream)
 
