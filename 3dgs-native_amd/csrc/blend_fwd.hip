@@ -1,24 +1,29 @@
 // blend_fwd.hip -- per-tile front-to-back alpha blending for gfx950.
 //
 // What the reference's wp_render_gaussians does per pixel (forward.py:385-515), restructured for CDNA4:
-// one 512-thread workgroup per 16x16 tile; each of its eight waves owns one 8x4 pixel block and blends TWO list entries
-// per wave instruction: lanes 0-31 hold the block's 32 pixels against entry A, lanes 32-63 the same pixels against the next
-// live entry B.  The tile's sorted list is staged through LDS in batches of 512 entries, each entry gathered ONCE per tile
-// as a single 64-byte record (the reference gathers four arrays per pixel per entry).  While staging, the thread that
-// fetched an entry tests it against the eight 8x4 blocks (exact convex minimum of the conic over the block rectangle vs
-// ln(255 o), conservative, behind an axis-aligned bounding-box pre-test) and stores an 8-bit hit mask; a wave then turns
-// the masks of a batch into its own compact list of live entries (ballot + mbcnt, indices in LDS) and walks that list two
-// entries at a time, so entries that cannot reach alpha >= 1/255 inside its block -- most of a tile's list -- cost it
-// nothing, and the walk needs no scalar bit loop.  The masks are also written out (GsrBinning.block_masks) so the
-// backward's per-block compaction reads one byte per entry instead of re-deriving the test from the records.
+// one 256-thread workgroup per 16x16 tile, each of its four waves owning one 8x8 pixel block (lane = pixel).  The tile's
+// sorted list is staged through LDS in batches of 256 entries, each entry gathered ONCE per tile as a single 64-byte record
+// (the reference gathers four arrays per pixel per entry).  While staging, the thread that fetched an entry tests it against
+// the tile's eight 8x4 blocks (exact convex minimum of the conic over the block rectangle vs ln(255 o), conservative, behind
+// an axis-aligned bounding-box pre-test; the exact test runs only for the blocks the box overlaps) and stores an 8-bit hit
+// mask.  A wave then turns the masks of a batch into its own compact list of live entries (ballot + mbcnt, byte offsets in
+// LDS) and walks that list with a two-deep software pipeline, so entries that cannot reach alpha >= 1/255 inside its block --
+// most of a tile's list -- cost it nothing and the walk needs no scalar bit loop (the round-1 kernel spent 43 M scalar
+// instructions there, more issue cycles than its vector work).  The masks are also written out (GsrBinning.block_masks) so
+// the backward's per-block compaction reads one byte per entry instead of re-deriving the test from the records.
 //
-// The two halves exchange (1 - alpha) with one v_permlane32_swap, so every lane follows the exact sequential transmittance
-// chain T -> T(1-aA) -> T(1-aA)(1-aB) in the reference's operation order: the discrete tests (power > 0, alpha < 1/255,
-// T < 1e-4) and therefore final_T and n_contrib agree with the CPU oracle except where exp() itself rounds differently
-// (exp is v_exp_f32(power * log2 e), relative error < 5e-7 for power in [-5.6, 0]).  A pair in which some pixel would
-// saturate takes a slower, fully masked path; all others run branch-free.  Colour is accumulated per half (the A chain and
-// the B chain) and added at the end: a re-association of the reference's sum, far inside the image tolerance.
-// `n_contrib` is the 1-based LIST position of the last contributing entry, so skipping dead entries does not change it.
+// Float operations are in the reference's order (no contraction in the transmittance chain; the conic is pre-scaled by exact
+// powers of two) so the discrete tests (power > 0, alpha < 1/255, T < 1e-4) agree with the CPU oracle except where exp()
+// itself rounds differently: exp is v_exp_f32(power * log2 e), relative error < 5e-7 for power in [-5.6, 0].  Colour is
+// accumulated with fused multiply-adds of c and (alpha T): the same sum to a few ulps.  The common step is branch-free and
+// mask-free: a finished (or off-image) pixel is parked at x = 1e15, where every entry's alpha underflows to 0; only a step in
+// which some pixel would saturate takes the masked path.  `n_contrib` is the 1-based LIST position of the last contributing
+// entry, so skipping dead entries does not change it.
+//
+// Measured and rejected in round 2: eight waves per tile, each blending TWO entries per instruction over an 8x4 block
+// (v_permlane32_swap hand-over of 1 - alpha): bit-identical results, but splats at C3 are as large as the blocks, so the finer
+// blocks cull almost nothing (168 live entries per 8x4 block against 168 per 8x8 block) and the pair step costs 28 vector
+// instructions against 2 x 22: 0.149 ms against 0.128 ms.
 #include "gsr_internal.h"
 
 // GSR_TIMELINE (diagnostic build only, never the product): per-phase shader-cycle totals over all waves
@@ -28,7 +33,7 @@ __device__ unsigned long long g_fwd_wave[TL_MAX_WAVES][8]; // one row per wave, 
 #define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
 #define TL_COUNT(k, v) tl_acc[k] += (v);
-#define TL_FLUSH if (lane == 0) { const int tw = (blockIdx.x * 8 + wv) & (TL_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_fwd_wave[tw][q] = tl_acc[q]; }
+#define TL_FLUSH if (lane == 0) { const int tw = (blockIdx.x * 4 + wv) & (TL_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_fwd_wave[tw][q] = tl_acc[q]; }
 #else
 #define TL_DECL
 #define TL(k)
@@ -38,42 +43,34 @@ __device__ unsigned long long g_fwd_wave[TL_MAX_WAVES][8]; // one row per wave, 
 
 namespace {
 
-constexpr int BATCH = 512;
-constexpr int NWAVES = 8;
+constexpr int BATCH = 256;
+constexpr int NWAVES = 4;
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// minimise 0.5*qa*u^2 + 0.5*qc*v^2 + qb*u*v over v in [vlo, vhi]
-__device__ __forceinline__ float edge_min_q(float qa, float qb, float qc, float u, float vlo, float vhi)
+// minimise 0.5*qa*u^2 + 0.5*qc*v^2 + qb*u*v over v in [vlo, vhi];  nbr = -qb / qc
+__device__ __forceinline__ float edge_min_q(float qa, float qb, float qc, float nbr, float u, float vlo, float vhi)
 {
-    float v = -qb * u * fast_rcp(qc);
+    float v = nbr * u;
     v = fminf(vhi, fmaxf(vlo, v));
     return 0.5f * (qa * u * u + qc * v * v) + qb * u * v;
 }
-// Can alpha reach 1/255 anywhere in pixels [x0,x0+7] x [y0,y0+3]?  Conservative (small slack).  The same test, with the same
+// Can alpha reach 1/255 anywhere in pixels [x0,x0+7] x [y0,y0+3]?  Conservative (small slack in `lim`).
+// alpha = o exp(power) >= 1/255  <=>  q(d) = 0.5 (a dx^2 + c dy^2) + b dx dy <= ln(255 o), d = centre - pixel.  q is a convex
+// quadratic, so its minimum over the rectangle is 0 if the centre is inside, else it lies on an edge whose supporting line
+// has the centre on its OUTER side (KKT: A (x* - c) = -lambda n with lambda >= 0 gives n.(c - x*) >= 0): for an axis-aligned
+// rectangle that is at most one vertical and one horizontal edge, each a clamped 1-D quadratic.  The same test, with the same
 // slack, is what the backward's own compaction applies when it has no masks (blend_bwd_splat.hip).
-__device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float lim, float x0, float y0)
+__device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, float cb, float cc, float nb_rc, float nb_ra, float lim, float x0,
+                                              float y0)
 {
     const float dxl = gx - (x0 + 7.0f), dxh = gx - x0, dyl = gy - (y0 + 3.0f), dyh = gy - y0;
-    float qmin;
-    if (dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f) qmin = 0.0f;
-    else {
-        qmin = edge_min_q(ca, cb, cc, dxl, dyl, dyh);
-        qmin = fminf(qmin, edge_min_q(ca, cb, cc, dxh, dyl, dyh));
-        qmin = fminf(qmin, edge_min_q(cc, cb, ca, dyl, dxl, dxh));
-        qmin = fminf(qmin, edge_min_q(cc, cb, ca, dyh, dxl, dxh));
-    }
+    const bool in_x = dxl <= 0.0f && dxh >= 0.0f, in_y = dyl <= 0.0f && dyh >= 0.0f;
+    const float qx = edge_min_q(ca, cb, cc, nb_rc, dxh < 0.0f ? dxh : dxl, dyl, dyh); // the vertical edge facing the centre
+    const float qy = edge_min_q(cc, cb, ca, nb_ra, dyh < 0.0f ? dyh : dyl, dxl, dxh); // the horizontal edge facing the centre
+    const float qmin = in_x ? (in_y ? 0.0f : qy) : (in_y ? qx : fminf(qx, qy));
     return qmin <= lim;
-}
-
-// both halves of the wave receive (value held by lanes 0-31, value held by lanes 32-63) of the same pixel
-__device__ __forceinline__ void halves(float v, float &lo, float &hi)
-{
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); // r[0] = {v.lo, v.lo}, r[1] = {v.hi, v.hi}
-    lo = __uint_as_float(r[0]);
-    hi = __uint_as_float(r[1]);
 }
 
 // LDS image of one staged entry: 48 bytes = {x, y, -a/2, -b | -c/2, opacity, r, g | b, 1/depth, -, -}.  The conic is stored as
@@ -84,14 +81,15 @@ __device__ __forceinline__ void halves(float v, float &lo, float &hi)
 // 4-bank groups) and lets the blend loop address all three pieces of a record from ONE byte offset, which is what the waves'
 // compacted lists hold.
 constexpr int REC_BYTES = 48;
-constexpr int LIST_PAD = 8; // sentinel offsets behind a wave's list: the pair loop reads up to three pairs ahead without bounds tests
+constexpr int LIST_PAD = 8;       // sentinel offsets behind a wave's list: the walk reads up to three entries ahead without bounds tests
+constexpr float PARKED_X = 1e15f; // x coordinate of a finished pixel: (-a/2 dx) dx ~ -1e30 a, so alpha underflows to exactly 0
 
-struct PairRec {
+struct StagedRec {
     float4 a, b;
     float2 c;
 };
 
-__global__ __launch_bounds__(512, 6) void blend_forward_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
+__global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
                                                             const int32_t *__restrict__ ranges,
                                                             const int32_t *__restrict__ point_list,
                                                             const BlendRec *__restrict__ rec, float *__restrict__ image,
@@ -103,22 +101,22 @@ __global__ __launch_bounds__(512, 6) void blend_forward_kernel(int W, int H, int
     __shared__ uint16_t s_list[NWAVES][BATCH + LIST_PAD];  // per wave: byte offsets (into s_rec) of its live entries, in list order
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int half = lane >> 5, p = lane & 31;
     const int tile = blockIdx.x;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const int pix_x = tile_x * 16 + (wv & 1) * 8 + (p & 7);
-    const int pix_y = tile_y * 16 + (wv >> 1) * 4 + (p >> 3);
-    float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
-    asm volatile("" : "+v"(pixf_x), "+v"(pixf_y)); // keep the converted coordinates in registers (hipcc re-converts them per entry otherwise)
+    const int pix_x = tile_x * 16 + (wv & 1) * 8 + (lane & 7);
+    const int pix_y = tile_y * 16 + (wv >> 1) * 8 + (lane >> 3);
     const float tx0 = (float)(tile_x * 16), ty0 = (float)(tile_y * 16);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int my_bits = 5 << ((wv >> 1) * 4 + (wv & 1)); // this wave's 8x8 block = the 8x4 blocks k0 and k0 + 2
 
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
     const int start = range.x, end = range.y;
 
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f; // T: the pixel's transmittance (same in both halves); c*: this half's chain
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f;
     int last = 0;
     bool done = !(pix_x < W && pix_y < H);
+    float pixf_x = done ? PARKED_X : (float)pix_x, pixf_y = (float)pix_y;
+    asm volatile("" : "+v"(pixf_x), "+v"(pixf_y)); // keep the converted coordinates in registers (hipcc re-converts them per entry otherwise)
     if (tid < 3) reinterpret_cast<float4 *>(s_rec + BATCH * REC_BYTES)[tid] = make_float4(0.f, 0.f, 0.f, 0.f); // the sentinel
 
     TL_DECL
@@ -158,7 +156,7 @@ __global__ __launch_bounds__(512, 6) void blend_forward_kernel(int W, int H, int
                 const float lx = a.x - hx - tx0, rx = a.x + hx - tx0, ly = a.y - hy - ty0, ry = a.y + hy - ty0; // box relative to the tile origin
                 // candidate blocks = those the box overlaps; the exact test runs once per candidate (most splats have one to four), the
                 // loop's trip count being the largest candidate count among the wave's 64 entries
-                int cand = 0;
+                int cand;
                 {
                     const int xm = (boxless || (lx <= 7.0f && rx >= 0.0f) ? 0x55 : 0) | (boxless || (lx <= 15.0f && rx >= 8.0f) ? 0xAA : 0);
                     int ym = 0;
@@ -167,10 +165,11 @@ __global__ __launch_bounds__(512, 6) void blend_forward_kernel(int W, int H, int
                         if (boxless || (ly <= (float)(4 * r + 3) && ry >= (float)(4 * r))) ym |= 3 << (2 * r);
                     cand = xm & ym;
                 }
+                const float nb_rc = -a.w * fast_rcp(b.x), nb_ra = -a.w * fast_rcp(a.z);
                 while (cand) {
                     const int k = __builtin_ctz(cand);
                     cand &= cand - 1;
-                    if (block_may_hit(a.x, a.y, a.z, a.w, b.x, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 4))) m |= 1 << k;
+                    if (block_may_hit(a.x, a.y, a.z, a.w, b.x, nb_rc, nb_ra, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 4))) m |= 1 << k;
                 }
             }
             s_mask[tid] = (uint8_t)m;
@@ -197,85 +196,76 @@ __global__ __launch_bounds__(512, 6) void blend_forward_kernel(int W, int H, int
         int n = 0;
         for (int g = 0; g < cnt; g += 64) {
             const int mv = (g + lane < cnt) ? (int)s_mask[g + lane] : 0;
-            const bool hit = ((mv >> wv) & 1) != 0;
+            const bool hit = (mv & my_bits) != 0;
             const unsigned long long bits = __ballot(hit);
             if (hit) s_list[wv][n + __popcll(bits & lt_mask)] = (uint16_t)((g + lane) * REC_BYTES);
             n += __popcll(bits);
         }
         if (lane < LIST_PAD) s_list[wv][n + lane] = (uint16_t)(BATCH * REC_BYTES);
         TL(4) // list build
-        TL_COUNT(7, (unsigned long long)((n + 1) / 2))
+        TL_COUNT(7, (unsigned long long)n)
 
-        // two entries per step: lanes 0-31 take list[k], lanes 32-63 list[k+1].  Two-deep software pipeline: the offsets of
-        // pair k+2 and the records of pair k+1 are in flight while pair k is blended.
-        const uint16_t *lp = &s_list[wv][half];
+        // walk the list; two-deep software pipeline: the offset of entry k+2 and the record of entry k+1 are in flight while
+        // entry k is blended
+        const uint16_t *lp = &s_list[wv][0];
         auto fetch = [&](int off) {
-            PairRec r;
+            StagedRec r;
             const float4 *q = reinterpret_cast<const float4 *>(s_rec + off);
             r.a = q[0]; r.b = q[1];
             r.c = *reinterpret_cast<const float2 *>(q + 2);
             return r;
         };
-        int off_cur = lp[0], off_nxt = lp[2];
-        PairRec cur = fetch(off_cur);
+        // Two register sets alternate (no register rotation); an odd list ends on a sentinel, which contributes nothing.
+#define GSR_BLEND(R, OFF)                                                                                                      \
+    {                                                                                                                         \
+        const float dx = R.a.x - pixf_x, dy = R.a.y - pixf_y;                                                                 \
+        const float power = (R.a.z * dx * dx + R.b.x * dy * dy) + R.a.w * dx * dy; /* see REC_BYTES: the reference's value */   \
+        const float alpha = fminf(0.99f, R.b.y * fast_exp(power));                                                            \
+        /* forward.py:480-484: skip when power > 0 or alpha < 1/255 -- as selects, not branches */                            \
+        const float t = power > 0.0f ? 0.0f : alpha;                                                                          \
+        const bool contributes = !(t < (1.0f / 255.0f));                                                                      \
+        const float a_eff = contributes ? t : 0.0f;                                                                           \
+        const float test_T = T * (1.0f - a_eff); /* forward.py:486 */                                                          \
+        if (__builtin_amdgcn_ballot_w64(test_T < 0.0001f) != 0ull) {                                                          \
+            /* some pixel saturates at this entry (forward.py:487-489): the entry is not applied there and the pixel ends */  \
+            const bool sat = contributes && (test_T < 0.0001f);                                                               \
+            const bool apply = contributes && !sat;                                                                           \
+            const float w = apply ? a_eff * T : 0.0f;                                                                         \
+            cr = __builtin_fmaf(R.b.z, w, cr); cg = __builtin_fmaf(R.b.w, w, cg);                                             \
+            cb = __builtin_fmaf(R.c.x, w, cb); cd = __builtin_fmaf(R.c.y, w, cd);                                             \
+            if (apply) { last_off = OFF; T = test_T; }                                                                        \
+            if (sat) pixf_x = PARKED_X; /* the pixel is finished (`done` is re-derived from this after the walk) */           \
+            if (__all(pixf_x == PARKED_X)) break; /* the wave's 64 pixels are saturated: nothing later can contribute */      \
+        } else {                                                                                                              \
+            const float w = a_eff * T;                                                                                        \
+            cr = __builtin_fmaf(R.b.z, w, cr); cg = __builtin_fmaf(R.b.w, w, cg);                                             \
+            cb = __builtin_fmaf(R.c.x, w, cb); cd = __builtin_fmaf(R.c.y, w, cd);                                             \
+            if (contributes) last_off = OFF;                                                                                  \
+            T = test_T;                                                                                                       \
+        }                                                                                                                     \
+    }
+        int off0 = lp[0], off1 = lp[1];
+        StagedRec r0 = fetch(off0);
         int last_off = -1;
         for (int k = 0; k < n; k += 2) {
-            const PairRec nxt = fetch(off_nxt);
-            const int off_n2 = lp[4];
+            const StagedRec r1 = fetch(off1);      // entry k+1 (or a sentinel)
+            const int off2 = lp[2];
+            GSR_BLEND(r0, off0)
+            r0 = fetch(off2);                      // entry k+2
+            off0 = off2;
+            const int off3 = lp[3];
             lp += 2;
-            const float dx = cur.a.x - pixf_x, dy = cur.a.y - pixf_y;
-            const float power = (cur.a.z * dx * dx + cur.b.x * dy * dy) + cur.a.w * dx * dy; // see REC_BYTES: the reference's value, bit for bit
-            const float alpha = fminf(0.99f, cur.b.y * fast_exp(power));
-            const bool valid = !done && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-            const float a_eff = valid ? alpha : 0.0f;
-            float omA, omB;
-            halves(1.0f - a_eff, omA, omB);      // (1 - alpha) of entry A and of entry B for this pixel; 1 where the entry does nothing
-            const float T1 = T * omA, T2 = T1 * omB; // the reference's test_T after A, after B (forward.py:486)
-            if (__builtin_amdgcn_ballot_w64(T2 < 0.0001f && !done) != 0ull) {
-                // some pixel saturates inside this pair: the exact sequential logic, lane by lane (forward.py:486-489: an entry that
-                // would push T below 1e-4 is not applied and ends the pixel)
-                const bool vA = omA < 1.0f, vB = omB < 1.0f;           // entry valid for this pixel (alpha >= 1/255 > 0)
-                const bool satA = vA && (T1 < 0.0001f);
-                const bool applyA = vA && !satA;
-                const float Ta = applyA ? T1 : T;
-                const float Tb = Ta * omB;
-                const bool satB = vB && !satA && (Tb < 0.0001f);
-                const bool applyB = vB && !satA && !satB;
-                const bool mine = half ? applyB : applyA;
-                const float w = mine ? alpha * (half ? Ta : T) : 0.0f;
-                cr = __builtin_fmaf(cur.b.z, w, cr); cg = __builtin_fmaf(cur.b.w, w, cg);
-                cb = __builtin_fmaf(cur.c.x, w, cb); cd = __builtin_fmaf(cur.c.y, w, cd);
-                if (mine) last_off = off_cur;
-                T = applyB ? Tb : Ta;
-                done = done || satA || satB;
-                if (__all(done)) break; // the wave's 32 pixels are saturated: nothing later in the list can contribute
-            } else {
-                const float w = a_eff * (half ? T1 : T);
-                cr = __builtin_fmaf(cur.b.z, w, cr); cg = __builtin_fmaf(cur.b.w, w, cg);
-                cb = __builtin_fmaf(cur.c.x, w, cb); cd = __builtin_fmaf(cur.c.y, w, cd);
-                if (valid) last_off = off_cur;
-                T = T2;
-            }
-            cur = nxt;
-            off_cur = off_nxt;
-            off_nxt = off_n2;
+            GSR_BLEND(r1, off1)
+            off1 = off3;
         }
+#undef GSR_BLEND
         // n_contrib = 1-based list position of the last contributing entry: offset / 48 by multiply-shift (exact below 2^16)
         if (last_off >= 0) last = base - start + (int)(((unsigned)last_off * 43691u) >> 21) + 1;
-        TL(5) // pair loop
+        done = pixf_x == PARKED_X;
+        TL(5) // list walk
     }
 
-    // add the two chains; lanes 0-31 write the block's pixels
-    {
-        float lo, hi;
-        halves(cr, lo, hi); cr = lo + hi;
-        halves(cg, lo, hi); cg = lo + hi;
-        halves(cb, lo, hi); cb = lo + hi;
-        halves(cd, lo, hi); cd = lo + hi;
-        halves(__int_as_float(last), lo, hi);
-        last = max(__float_as_int(lo), __float_as_int(hi));
-    }
-    if (half == 0 && pix_x < W && pix_y < H) {
+    if (pix_x < W && pix_y < H) {
         const size_t px = (size_t)pix_y * W + pix_x;
         final_T[px] = T;
         n_contrib[px] = last;
@@ -303,7 +293,7 @@ hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, cons
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(512), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
                        ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ for _ in range(3):
     gsr.render_gaussians(**kw)
 torch.cuda.synchronize()
 tiles = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
-waves = tiles * 8
+waves = tiles * 4
 arr = np.zeros((waves, 8), np.uint64)
 assert L.gsr_debug_fwd_phases(arr.ctypes.data_as(C.c_void_p), waves) == 0
 names = ["top barrier (incl. launch->first)", "wait gathered records", "staging (LDS image + masks)", "staging barrier", "list build", "pair loop", "epilogue"]
