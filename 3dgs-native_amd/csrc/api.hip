@@ -41,36 +41,22 @@ int tile_bits(int tiles)
     return b;
 }
 
-// Binning workspace.  One-pass tile binning (tile_bin.hip; grids of up to GSR_BIN_MAX_TILES tiles): per-chunk tile histograms
-// and their scans.  Radix path (larger grids, or GSR_DEBUG bit 7): the expanded (tile, id) items, ping-pong, and the radix
-// histograms.  The two never coexist; the workspace is sized for whichever the grid takes.
 struct BinWs {
-    bool one_pass;
-    void *bin_hist, *bin_seg, *bin_base; // one-pass
-    int32_t *hist;       // [256 * nb]      radix
+    int32_t *hist;       // [256 * nb]
     int32_t *totals;     // [256]
     uint64_t *tile_a;    // [D]
     uint64_t *tile_b;    // [D]
     size_t bytes;
 };
-bool use_one_pass(int tiles) { return gsr_bin_supported(tiles) && !(gsr_debug_flags & 128); }
-BinWs carve_bin(void *base, int64_t N, int64_t D, int tiles)
+BinWs carve_bin(void *base, int64_t N, int64_t D)
 {
     Carver c(base);
-    BinWs w = {};
+    BinWs w;
     (void)N;
-    w.one_pass = use_one_pass(tiles);
-    if (w.one_pass) {
-        const BinPlan p = gsr_bin_plan(D, tiles);
-        w.bin_hist = c.take<char>(p.hist_bytes);
-        w.bin_seg = c.take<char>(p.seg_bytes);
-        w.bin_base = c.take<char>(p.base_bytes);
-    } else {
-        w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(D) + 1));
-        w.totals = c.take<int32_t>(256);
-        w.tile_a = c.take<uint64_t>((size_t)D);
-        w.tile_b = c.take<uint64_t>((size_t)D);
-    }
+    w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(D) + 1));
+    w.totals = c.take<int32_t>(256);
+    w.tile_a = c.take<uint64_t>((size_t)D);
+    w.tile_b = c.take<uint64_t>((size_t)D);
     w.bytes = c.off + 256;
     return w;
 }
@@ -290,7 +276,6 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
     w.totals = c.take<int32_t>(256);
-    w.kidx = c.take<int32_t>((size_t)GSR_KIDX_ENTRIES);
     w.bytes = c.off + 256;
     return w;
 }
@@ -324,12 +309,7 @@ const char *gsr_strerror(int code)
 }
 
 size_t gsr_geom_workspace_bytes(int64_t N) { return gsr_carve_geom(nullptr, N < 0 ? 0 : N).bytes; }
-size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H)
-{
-    read_tuning();
-    const int tiles = ((W > 0 ? W : 1) + GSR_TILE - 1) / GSR_TILE * (((H > 0 ? H : 1) + GSR_TILE - 1) / GSR_TILE);
-    return carve_bin(nullptr, N < 0 ? 0 : N, D < 0 ? 0 : D, tiles).bytes;
-}
+size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t, int32_t) { return carve_bin(nullptr, N < 0 ? 0 : N, D < 0 ? 0 : D).bytes; }
 size_t gsr_backward_workspace_bytes(int64_t N, int64_t, int32_t, int32_t) { return carve_bwd(nullptr, N < 0 ? 0 : N).bytes; }
 
 int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, void *geom_ws, size_t geom_ws_bytes,
@@ -370,7 +350,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
         // the last pass also carries each Gaussian's tile rectangle and tile count to its sorted position
         HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.totals, N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
         mark(st, 3, s);
-        HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s, ws.kidx));
+        HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s));
         mark(st, 4, s);
     }
     HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting
@@ -413,22 +393,11 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     // D must be the count gsr_forward_count returned for the items now in geom_ws (see CountNote above)
     if (check_count(geom_ws, N, D) != 1) return GSR_E_CAPACITY;
     const GeomWs gw = gsr_carve_geom(geom_ws, N);
-    const BinWs bw = carve_bin(bin_ws, N, D, tiles);
+    const BinWs bw = carve_bin(bin_ws, N, D);
 
     const int st = t_fwd_record;
     t_fwd_record = -1;
     mark(st, 5, s);
-    if (bw.one_pass) {
-        // 3-5. one-pass tile binning (tile_bin.hip): count the pairs per (chunk, tile), scan, then write every pair's Gaussian id
-        //      straight to its place in point_list; `ranges` falls out of the scan.  Stage slots: "expand" = the counting
-        //      kernel, "tile_sort" = scans + scatter, "ranges" = nothing.
-        HIP_TRY(gsr_launch_bin_count(gw, N, D, cam.grid_x, tiles, bw.bin_hist, s));
-        mark(st, 6, s);
-        HIP_TRY(gsr_launch_bin_scatter(gw, N, D, cam.grid_x, tiles, bw.bin_hist, bw.bin_seg, bw.bin_base, binning->point_list,
-                                       binning->ranges, s));
-        mark(st, 7, s);
-        mark(st, 8, s);
-    } else {
     // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile << id_shift | id) items.  When the tile
     //    bits and the id bits fit one 32-bit word (800x800 with 1M Gaussians: 12 + 20) the items are uint32, which
     //    halves the traffic of the expansion, both partition passes and the range scan.
@@ -453,7 +422,6 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     // 5. point_list + ranges
     HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, id_shift, item_bytes, s));
     mark(st, 8, s);
-    }
     // 6. blend
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, s));
     mark(st, 9, s);

@@ -45,10 +45,8 @@ struct GeomWs {
     int32_t *scan_tmp;    // block sums for the scans
     int32_t *hist;        // [256 * nb(N)] radix block histograms
     int32_t *totals;      // [256]
-    int32_t *kidx;        // [GSR_KIDX_ENTRIES] kidx[m] = depth-order index of the Gaussian that owns pair m * 1024 (written by the depth-order scan)
     size_t bytes;
 };
-#define GSR_KIDX_ENTRIES ((int)(GSR_MAX_RENDERED >> 10) + 2)
 GeomWs gsr_carve_geom(void *base, int64_t N);
 
 // ---- launchers (host functions; each enqueues on `s` and returns hipGetLastError()) ----
@@ -58,8 +56,7 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 // mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
-                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s,
-                           int32_t *kidx = nullptr /* mode 2 only: also index the owners of every 1024th unit (GeomWs::kidx) */);
+                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s);
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096
@@ -75,18 +72,6 @@ hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
                              hipStream_t s);
-// One-pass tile binning (tile_bin.hip): point_list + ranges straight from the depth-sorted rectangles, for grids of up to
-// GSR_BIN_MAX_TILES tiles (its per-wave tile counters and base row live in LDS: 20 bytes per tile); larger grids take the radix passes above.
-#define GSR_BIN_MAX_TILES 7168
-struct BinPlan {
-    int S, nchunks, cps, nsegs;
-    size_t hist_bytes, seg_bytes, base_bytes;
-};
-BinPlan gsr_bin_plan(int64_t D, int tiles);
-bool gsr_bin_supported(int tiles);
-hipError_t gsr_launch_bin_count(const GeomWs &gw, int64_t N, int64_t D, int grid_x, int tiles, void *hist, hipStream_t s);
-hipError_t gsr_launch_bin_scatter(const GeomWs &gw, int64_t N, int64_t D, int grid_x, int tiles, const void *hist, void *seg, void *base,
-                                  int32_t *point_list, int32_t *ranges, hipStream_t s);
 hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift,
                              int item_bytes, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
@@ -105,16 +90,15 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
-// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks, bit 7 the radix
-// partition of expanded (tile, id) items instead of the one-pass tile binning -- same results by other code paths
-// (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
+// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks -- same results by
+// other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
 // one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->
 // libgsr_hip_ablate.so, -DGSR_ABLATE, used by tools/stage_bench.sh) and are compiled out of libgsr_hip.so.
 #ifdef GSR_ABLATE
-#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128)
+#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64)
 #define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
 #else
-#define GSR_DEBUG_ALLOWED (32 | 64 | 128)
+#define GSR_DEBUG_ALLOWED (32 | 64)
 #define GSR_ABL(flags, bit) false
 #endif
 extern int gsr_debug_flags;

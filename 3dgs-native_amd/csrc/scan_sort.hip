@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 
 template <int MODE>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
-                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out, int32_t *__restrict__ kidx)
+                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -112,15 +112,6 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
         const int inc = wave_incl_scan(v[r]);
         const int64_t k = base + r * 64 + lane;
         if (k == n - 1) total = carry + inc;
-        if (MODE == 2 && kidx) {
-            // index for the one-pass tile binning (tile_bin.hip): item k owns the units [e, e + c); for every multiple of 1024
-            // in that range, kidx[multiple / 1024] = k.  Nearly every item owns none or one; a screen-filling one owns a few.
-            const int c = v[r], e = carry + inc - c;
-            if (k < n && c > 0) {
-                const int m1 = min((e + c - 1) >> 10, GSR_KIDX_ENTRIES - 1);
-                for (int m = (e + 1023) >> 10; m <= m1; ++m) kidx[m] = (int32_t)k;
-            }
-        }
         v[r] = carry + (MODE == 0 ? inc : inc - v[r]); // mode 0 inclusive, mode 2 exclusive
         carry += __shfl(inc, 63, 64);
     }
@@ -425,7 +416,7 @@ __global__ __launch_bounds__(256) void ranges_kernel(const ItemT *__restrict__ i
 } // namespace
 
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
-                           int32_t *total_out, hipStream_t s, int32_t *kidx)
+                           int32_t *total_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
@@ -433,10 +424,10 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     (void)items;
     if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out, (int32_t *)nullptr);
+        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else if (mode == 2) {
         hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out, kidx);
+        hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else {
         return hipErrorInvalidValue;
     }
