@@ -39,6 +39,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMD-32, same guide
+# Cycles ONE SIMD needs per wave64 vector instruction: a SIMD-32 issues a plain VALU op over 2 cycles; DPP (and packed-f32) ops
+# go at half that rate, v_exp / v_rcp / v_log / v_sqrt at a quarter.  tools/valu_rate measures 2.3 / 4.2-4.5 / 8.2 chip-wide with
+# 8 waves per SIMD (profiles/r02_valu_issue_costs.txt); the roof below is priced at the architectural 2 / 4 / 8.
+VALU_ISSUE_CYCLES = {"plain": 2.0, "dpp": 4.0, "transcendental": 8.0}
+
+
+def roofline_valu(stage, counters, avg_ms):
+    """Vector-issue roof of a blend kernel: wave-instructions (rocprofv3 SQ counters of THIS build, profiles/sq_counters.json) x
+    issue cycles, over the SIMD cycles the launch had (1024 SIMDs x the stage's live HIP-event time x 2.4 GHz).  DPP ops have
+    no counter of their own: the backward blend executes exactly 12 (two 6-step wave scans) and 2 transcendentals (exp, rcp)
+    per (bucket, pixel) step and none elsewhere on the mask-driven path bench.py runs, so DPP = 6 x transcendentals there; the
+    forward has none.  Both kernels are built without v_pk_*_f32."""
+    insts, trans = counters["SQ_INSTS_VALU"], counters.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    dpp = 6.0 * trans if stage == "blend_bwd" else 0.0
+    plain = insts - trans - dpp
+    c = VALU_ISSUE_CYCLES
+    need = plain * c["plain"] + dpp * c["dpp"] + trans * c["transcendental"]
+    have = SIMDS * avg_ms * 1e-3 * MAX_CLOCK_HZ
+    return {"bound": "valu_issue", "kernel": counters.get("kernel"), "wave_instructions": int(insts), "transcendental": int(trans), "dpp": int(dpp),
+            "scalar_instructions": int(counters.get("SQ_INSTS_SALU", 0)), "issue_cycles": int(need), "simd_cycles": int(have),
+            "frac": round(need / have, 4), "frac_if_every_op_took_2_cycles": round(insts * 2.0 / have, 4), "avg_ms": round(avg_ms, 4)}
 
 
 def stage_bytes(N, Nv, D, P, Tn):
@@ -244,6 +266,16 @@ def main():
                                             "achieved": round(B / (gpu_ms * 1e-3) / 1e9, 2),
                                             "frac": round(B / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                                "stage_ms": {k: round(v, 4) for k, v in stages.items()}}
+            # the two blend kernels are not HBM-bound: their roof is vector-instruction issue (SURVEY.md section 8(d) "secondary
+            # practical bound"), priced from the SQ counters measured on this very build (null when the build has none on file)
+            qpath = os.path.join(ROOT, "profiles", "sq_counters.json")
+            out["roofline_valu"] = None
+            if os.path.exists(qpath):
+                with open(qpath) as f:
+                    qj = json.load(f)
+                if qj.get("_build") == build and args.config in qj:
+                    out["roofline_valu"] = {st: roofline_valu(st, cnts, timed[st]) for st, cnts in qj[args.config].items() if st in timed}
+                    out["roofline_valu"]["counters"] = qj.get("_round")
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             okw = dict(fkw)
