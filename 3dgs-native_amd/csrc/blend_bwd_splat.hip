@@ -27,6 +27,21 @@
 // This kernel re-associates float sums anyway (quirk Q15), so fused multiply-adds are allowed here.
 #pragma clang fp contract(fast)
 
+// GSR_TIMELINE (diagnostic build only, never the product): per-phase shader cycles of every wave (tools/bwd_timeline.py)
+#ifdef GSR_TIMELINE
+constexpr int TLB_MAX_WAVES = 1 << 17;
+__device__ unsigned long long g_bwd_wave[TLB_MAX_WAVES][8];
+#define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
+#define TL_COUNT(k, v) tl_acc[k] += (v);
+#define TL_FLUSH if (threadIdx.x == 0) { const int tw = blockIdx.x & (TLB_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_bwd_wave[tw][q] = tl_acc[q]; }
+#else
+#define TL_DECL
+#define TL(k)
+#define TL_COUNT(k, v)
+#define TL_FLUSH
+#endif
+
 namespace {
 
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
@@ -143,6 +158,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
     const int start = range.x, end = range.y;
     if (end <= start) return;
+    TL_DECL
 
     // lane q prepares the constants of pixel q of the block
     const int bx0 = tile_x * 16 + (sub % NBX) * BW, by0 = tile_y * 16 + (sub / NBX) * BH;
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
 
     int cursor = hi_all; // next list index (exclusive) to pull candidates from, moving towards `start`
     int head = 0, qn = 0; // ring state (wave-uniform)
+    TL(0) // prologue
     for (;;) {
         // ---- fill: pull candidates (deepest first) until a full bucket is queued or the list is exhausted ----
         while (qn < 64 && cursor > start) {
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         }
         if (qn == 0) break;
         __syncthreads();
+        TL(1) // fill
 
         // ---- one bucket: lane k takes the k-th queued entry (still deepest first) ----
         const int n = min(64, qn);
@@ -221,6 +239,11 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             b = rp[1]; // con.c opacity r g
             colb = rp[2].x;
         }
+#ifdef GSR_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TL(2) // record gather
+        TL_COUNT(6, 1ull)
+#endif
         const int idx_min = __shfl(idx, n - 1, 64); // shallowest entry of the bucket
         head = (head + n) & (QCAP - 1);
         qn -= n;
@@ -236,6 +259,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             const float4 pb = s_pb[q];
             const int pkept = __float_as_int(pb.w);
             if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
+            TL_COUNT(7, 1ull)
             const float4 pa = s_pa[q];
             const float2 carry = s_carry[q];
             const float d_x = a.x - pa.x, d_y = a.y - pa.y;
@@ -266,6 +290,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                 Sxx += hx * d_x; Sxy += hx * d_y; Syy += hy * d_y;
             }
         }
+        TL(3) // pixel loop
         // dL/dmean2D = dL/dG * dG/ddel * 0.5*(W,H), dG/ddelx = -G (a dx + b dy); dL/dconic = -0.5 h (dx^2, dx dy, dy^2)
         const float g_mx = -(a.z * S1 + a.w * S2) * ddelx_dx;
         const float g_my = -(b.x * S2 + a.w * S1) * ddely_dy;
@@ -284,7 +309,9 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             if (c < 9 && eid >= 0 && !GSR_ABL(dbg, 1)) unsafeAtomicAdd(&acc[eid].f[c], s_g[e][c]);
         }
         __syncthreads();
+        TL(4) // flush
     }
+    TL_FLUSH
 }
 
 // Rebuild blend records from the forward's per-Gaussian outputs (backward() receives them as
@@ -314,6 +341,14 @@ hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, h
                        g.depths, rec, N);
     return hipGetLastError();
 }
+
+#ifdef GSR_TIMELINE
+extern "C" int gsr_debug_bwd_phases(unsigned long long *out /* [waves][8] */, int waves)
+{
+    if (waves > TLB_MAX_WAVES) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_wave), sizeof(unsigned long long) * 8 * (size_t)waves) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int gsr_bwd_block = 32;
 int gsr_debug_flags = 0; // see gsr_internal.h
