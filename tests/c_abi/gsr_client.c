@@ -1,4 +1,5 @@
-/* gsr_client.c -- a plain C program (gcc, no torch, no Python, no C++) that drives libgsr_hip.so through include/gsr.h:
+/* gsr_client.c -- a plain C program (gcc, no torch, no Python, no C++) that drives libgsr_hip.so (or, built with
+ * -DGSR_CLIENT_CPU, the oracle's libgsr_cpu.so) through include/gsr.h:
  * the drop-in boundary is a C ABI over caller-owned device memory and this is the proof.  It reads one scene + camera +
  * dL/dpixels from a flat binary file, runs gsr_forward_count / gsr_forward_render / gsr_backward with buffers it allocates
  * with hipMalloc, and writes every output to a flat binary file; tests/test_gpu_c_abi.py compares that file with the CPU
@@ -9,16 +10,34 @@
  * output: int64 D; int32 radii[N], offsets[N]; float xy[2N], depths[N], cov3D[6N], rgb[3N], conic[4N], clamped[3N];
  *         int32 point_list[D], ranges[2T]; float image[3WH], inv_depth[WH], final_T[WH]; int32 n_contrib[WH];
  *         float dmean3D[3N], dscale[3N], drot[4N], dopacity[N], dshs[48N], dcolor[3N], dmean2D[3N], dconic[4N] */
-#include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "gsr.h"
 
-#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d HIP error %d\n", __FILE__, __LINE__, (int)e_); return 2; } } while (0)
 #define CHECK_GSR(x) do { int r_ = (x); if (r_ != GSR_OK) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, gsr_strerror(r_)); return 3; } } while (0)
 
+/* The same program is built twice (tests/c_abi/Makefile): `gsr_client` against libgsr_hip.so with the buffers in device
+ * memory, and -DGSR_CLIENT_CPU `gsr_client_cpu` against oracle/libgsr_cpu.so -- the CPU oracle behind the identical ABI --
+ * with the buffers in host memory.  Everything below the three helpers is shared. */
+#ifdef GSR_CLIENT_CPU
+#define CHECK_HIP(x) do { if ((x) != 0) return 2; } while (0)
+typedef void *hipStream_t;
+static int hipStreamCreate(hipStream_t *s) { *s = NULL; return 0; }
+static int hipStreamSynchronize(hipStream_t s) { (void)s; return 0; }
+static void *dev_alloc(size_t bytes) { return aligned_alloc(64, ((bytes ? bytes : 4) + 63) & ~(size_t)63); }
+static void *dev_upload(FILE *f, size_t bytes)
+{
+    void *d = dev_alloc(bytes);
+    if (!d || (bytes && fread(d, 1, bytes, f) != bytes)) { fprintf(stderr, "short read\n"); exit(4); }
+    return d;
+}
+static void dump(FILE *f, const void *d, size_t bytes) { fwrite(d, 1, bytes, f); }
+#else
+#include <hip/hip_runtime_api.h>
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d HIP error %d\n", __FILE__, __LINE__, (int)e_); return 2; } } while (0)
 static void *dev_alloc(size_t bytes) { void *p = NULL; return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? p : NULL; }
 static void *dev_upload(FILE *f, size_t bytes)
 {
@@ -35,6 +54,7 @@ static void dump(FILE *f, const void *d, size_t bytes)
     fwrite(h, 1, bytes, f);
     free(h);
 }
+#endif
 
 int main(int argc, char **argv)
 {
@@ -75,7 +95,9 @@ int main(int argc, char **argv)
                    dev_alloc(12 * n), dev_alloc(16 * n), NULL};
     const size_t bwd_bytes = gsr_backward_workspace_bytes(N, D, W, H);
     void *bwd_ws = dev_alloc(bwd_bytes);
+#ifndef GSR_CLIENT_CPU
     g.blend_records = geom_ws; /* still untouched: the backward reuses the forward's records */
+#endif
     CHECK_GSR(gsr_backward(&sc, &cam, &g, &bin, &img, dpix, &gr, bwd_ws, bwd_bytes, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
 

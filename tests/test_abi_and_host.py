@@ -269,3 +269,34 @@ def test_arena_offsets_are_16_byte_aligned():
             assert all(o[k] + sizes[k] <= o[k + 1] for k in range(len(sizes)))
             assert o[-1] - sum(sizes) <= 3 * (len(sizes) - 1)
     assert d.arena_offsets(1000) == [0, 3000, 6000, 10000, 11000, 59000]      # N % 4 == 0: the plain 3N|3N|4N|N|48N layout
+
+
+def test_cpu_library_has_the_same_abi_and_reproduces_the_oracle(oracle, cameras, scenes, tmp_path):
+    """oracle/libgsr_cpu.so (test infrastructure): the CPU oracle behind the product's own C ABI -- SURVEY.md section 8(b)'s
+    "identical symbol set".  Every symbol include/gsr.h declares is exported, and the plain-C client of tests/c_abi, built
+    against it with host buffers, reproduces oracle.py bit for bit (both run the same gsro_* functions)."""
+    import re
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c_abi"), "gsr_client_cpu"])
+    hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    declared = set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", hdr))
+    cpu = C.CDLL(os.path.join(ROOT, "oracle", "libgsr_cpu.so"))
+    for name in sorted(declared):
+        assert hasattr(cpu, name), f"{name} declared in gsr.h but missing from libgsr_cpu.so"
+    assert cpu.gsr_abi_version() == sub("_lib").lib().gsr_abi_version() and cpu.gsr_build_flags() == 2
+    from test_gpu_c_abi import run_client
+    from conftest import backward_kwargs, render_kwargs
+    W, H, n = 96, 64, 400
+    scene = scenes.synthetic_scene(n, 0.06, 0.5, seed=4)
+    cam = lego_camera(cameras, frame=1, width=W, height=H)
+    kw = render_kwargs(scene, cam, width=W, height=H)
+    dpix = (np.random.default_rng(2).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3)).astype(np.float32)
+    image, inv_depth, buf, grads = run_client(os.path.join(ROOT, "tests", "c_abi", "gsr_client_cpu"), scene, kw, dpix, W, H, n, tmp_path)
+    ref = oracle.render_gaussians(**kw)
+    np.testing.assert_array_equal(image, ref[0])
+    np.testing.assert_array_equal(inv_depth, ref[1])
+    for k in ("radii", "point_offsets", "point_list", "ranges", "n_contrib", "final_Ts", "colors", "conic_opacity", "cov3Ds"):
+        np.testing.assert_array_equal(buf[k], np.asarray(ref[2][k]).reshape(buf[k].shape), err_msg=k)
+    g_ref = oracle.backward(**backward_kwargs(scene, cam, kw, ref[2], dpix))
+    for k in ("dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dshs", "dL_dcolor", "dL_dmean2D", "dL_dconic"):
+        np.testing.assert_array_equal(grads[k], np.asarray(g_ref[k]).reshape(grads[k].shape), err_msg=k)

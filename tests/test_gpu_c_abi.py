@@ -15,30 +15,27 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.join(ROOT, "tests", "c_abi")
 
 
-def _client():
-    exe = os.path.join(HERE, "gsr_client")
+def _client(name="gsr_client"):
+    exe = os.path.join(HERE, name)
     if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", HERE])
+        subprocess.check_call(["make", "-s", "-C", HERE, name])
     return exe
 
 
-def test_plain_c_client_matches_oracle(oracle, cameras, scenes, tmp_path):
-    _lib, _host = sub("_lib"), sub("_host")
-    W, H, n, degree = 176, 144, 3000, 3
-    scene = scenes.synthetic_scene(n, 0.04, 0.5, seed=21)
-    cam = lego_camera(cameras, frame=2, width=W, height=H)
-    kw = render_kwargs(scene, cam, width=W, height=H, degree=degree)
-    dpix = (np.random.default_rng(7).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3)).astype(np.float32)
+def run_client(exe, scene, kw, dpix, W, H, n, tmp_path, degree=3):
+    """Write the flat input file, run the plain-C client, parse its flat output: (image, inv_depth, buffers, grads)."""
+    _host = sub("_host")
     cstruct = _host.make_camera(kw["viewmatrix"], kw["projmatrix"], kw["campos"], kw["background"], kw["tan_fovx"], kw["tan_fovy"], W, H)
     f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32)).tobytes()
-    with open(tmp_path / "in.bin", "wb") as f:
+    tag = os.path.basename(exe)
+    with open(tmp_path / f"in_{tag}.bin", "wb") as f:
         f.write(np.int64(n).tobytes() + np.array([W, H, degree, 0, 0, 0], np.int32).tobytes() + bytes(cstruct))
         for k in ("means", "scales", "rotations", "opacities", "shs"):
             f.write(f32(scene[k]))
         f.write(f32(dpix))
-    r = subprocess.run([_client(), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, str(tmp_path / f"in_{tag}.bin"), str(tmp_path / f"out_{tag}.bin")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    blob = open(tmp_path / "out.bin", "rb").read()
+    blob = open(tmp_path / f"out_{tag}.bin", "rb").read()
     D = int(np.frombuffer(blob, np.int64, 1)[0])
     off = 8
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -60,6 +57,19 @@ def test_plain_c_client_matches_oracle(oracle, cameras, scenes, tmp_path):
              "dL_dopacity": take(f4, n, (n,)), "dL_dshs": take(f4, 48 * n, (16 * n, 3)), "dL_dcolor": take(f4, 3 * n, (n, 3)),
              "dL_dmean2D": take(f4, 3 * n, (n, 3)), "dL_dconic": take(f4, 4 * n, (n, 4)), "dL_dcov3D": np.zeros((n, 6), f4)}
     assert off == len(blob)
+    return image, inv_depth, buf, grads
+
+
+def test_plain_c_client_matches_oracle(oracle, cameras, scenes, tmp_path):
+    _lib, _host = sub("_lib"), sub("_host")
+    W, H, n, degree = 176, 144, 3000, 3
+    scene = scenes.synthetic_scene(n, 0.04, 0.5, seed=21)
+    cam = lego_camera(cameras, frame=2, width=W, height=H)
+    kw = render_kwargs(scene, cam, width=W, height=H, degree=degree)
+    dpix = (np.random.default_rng(7).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3)).astype(np.float32)
+    cstruct = _host.make_camera(kw["viewmatrix"], kw["projmatrix"], kw["campos"], kw["background"], kw["tan_fovx"], kw["tan_fovy"], W, H)
+    image, inv_depth, buf, grads = run_client(_client(), scene, kw, dpix, W, H, n, tmp_path, degree)
+    D = len(buf["point_list"])
 
     ref = oracle.render_gaussians(**kw)
     assert D == len(ref[2]["point_list"]) > 1000
@@ -69,3 +79,20 @@ def test_plain_c_client_matches_oracle(oracle, cameras, scenes, tmp_path):
     g_ref = oracle.backward(**backward_kwargs(scene, cam, kw, {**buf, "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]}, dpix))
     parity.compare_backward(grads, g_ref)
     assert C.sizeof(_lib.GsrCamera) == len(bytes(cstruct))
+
+
+def test_same_client_against_both_libraries(cameras, scenes, tmp_path):
+    """libgsr_hip.so and the oracle's libgsr_cpu.so export the same ABI; the SAME plain-C program,
+    built once per library, is run on the same input file and the two dumps are diffed -- byte for byte on every integer
+    output, under tests/parity.py on the floats."""
+    W, H, n = 208, 160, 5000
+    scene = scenes.synthetic_scene(n, 0.04, 0.6, seed=33)
+    cam = lego_camera(cameras, frame=6, width=W, height=H)
+    kw = render_kwargs(scene, cam, width=W, height=H)
+    dpix = (np.random.default_rng(8).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3)).astype(np.float32)
+    gi, gd, gb, gg = run_client(_client(), scene, kw, dpix, W, H, n, tmp_path)
+    ci, cd, cb, cg = run_client(_client("gsr_client_cpu"), scene, kw, dpix, W, H, n, tmp_path)
+    for k in ("radii", "point_offsets", "point_list", "ranges"):
+        assert gb[k].tobytes() == cb[k].tobytes(), k                      # byte for byte
+    parity.compare_forward((gi, gd, gb), (ci, cd, cb))
+    parity.compare_backward(gg, cg)
