@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             n += __popcll(bits);
         }
         if (lane < LIST_PAD) s_list[wv][n + lane] = (uint16_t)(BATCH * REC_BYTES);
+        // lanes read list entries other lanes wrote: in order in hardware, but the compiler must not move the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         TL(4) // list build
         TL_COUNT(7, (unsigned long long)n)
 

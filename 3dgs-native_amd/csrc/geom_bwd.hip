@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     g_m2d[0] = a0.w; g_m2d[1] = a1.x;
     g_con[0] = a1.y; g_con[1] = a1.z; g_con[2] = a1.w; // d/da, d/db, d/dc
     // API-layout copies of the blend-stage gradients
-    dL_dcolor[3 * idx] = g_col[0]; dL_dcolor[3 * idx + 1] = g_col[1]; dL_dcolor[3 * idx + 2] = g_col[2];
-    dL_dmean2D[3 * idx] = g_m2d[0]; dL_dmean2D[3 * idx + 1] = g_m2d[1]; dL_dmean2D[3 * idx + 2] = 0.0f;
+    // (dL_dcolor and dL_dmean2D: 12-byte rows, written wave-cooperatively at the end of the kernel)
     *reinterpret_cast<float4 *>(dL_dconic + 4 * idx) = make_float4(g_con[0], g_con[1], 0.0f, g_con[2]);
     dL_dopacity[idx] = a8;
 
@@ -313,11 +312,8 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
         }
     }
 
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { dL_dmean3D[3 * idx + k] = o_mean[k]; dL_dscale[3 * idx + k] = o_scale[k]; }
     *reinterpret_cast<float4 *>(dL_drot + 4 * idx) = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
     if (dL_drgb) {
-        dL_drgb[3 * idx] = o_rgb[0]; dL_drgb[3 * idx + 1] = o_rgb[1]; dL_drgb[3 * idx + 2] = o_rgb[2];
         if (idx == 0) { // the payload's trailer: where this view was taken from
             dL_drgb[3 * N] = cam.campos[0]; dL_drgb[3 * N + 1] = cam.campos[1]; dL_drgb[3 * N + 2] = cam.campos[2]; dL_drgb[3 * N + 3] = 0.0f;
         }
@@ -325,6 +321,15 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     // coefficients that got no gradient (culled Gaussian, lower degree) are zero, as in the reference's zero-initialised array
     for (int k = sh_written * 3; k < 48; ++k) row[k] = 0.0f;
     } // in_range
+    // the 12-byte-row outputs leave through the pad float4 of the wave's LDS rows as whole float4 lines (sh_stage.h): as
+    // per-lane scalar stores each of these arrays cost three instructions over 64 partial lines
+    if (rows_valid > 0) {
+        wave_store_vec3_in_pad(dL_dcolor + 3 * wave_row0, lds_wave, lane, rows_valid, g_col[0], g_col[1], g_col[2]);
+        wave_store_vec3_in_pad(dL_dmean2D + 3 * wave_row0, lds_wave, lane, rows_valid, g_m2d[0], g_m2d[1], 0.0f);
+        wave_store_vec3_in_pad(dL_dmean3D + 3 * wave_row0, lds_wave, lane, rows_valid, o_mean[0], o_mean[1], o_mean[2]);
+        wave_store_vec3_in_pad(dL_dscale + 3 * wave_row0, lds_wave, lane, rows_valid, o_scale[0], o_scale[1], o_scale[2]);
+        if (dL_drgb) wave_store_vec3_in_pad(dL_drgb + 3 * wave_row0, lds_wave, lane, rows_valid, o_rgb[0], o_rgb[1], o_rgb[2]);
+    }
     __syncthreads();
     if (dL_dshs && rows_valid > 0) sh_rows_store(reinterpret_cast<float4 *>(dL_dshs) + wave_row0 * 12, lds_wave, lane, rows_valid);
 }

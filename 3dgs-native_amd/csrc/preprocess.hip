@@ -215,26 +215,32 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                     o_rgb[c] = r;
                 }
     }
+    // ---- outputs.  Everything that is a whole 4-, 8- or 16-byte element per Gaussian is one coalesced store per array; the
+    // 12-, 24- and 64-byte rows (colour, clamp flags, Sigma3D, blend record) go out through the wave's LDS area -- the SH image
+    // is dead by now -- as whole float4 lines (sh_stage.h, wave_store_rows): as per-lane strided stores they were 9 of the
+    // kernel's 17 store instructions, each touching 64 partial lines.
+    const int rows_valid = (int)min((int64_t)64, N - wave_row0); // > 0: the grid covers exactly ceil(N / 256) blocks... a wave past N has <= 0
+    float *stage = reinterpret_cast<float *>(lds_wave);
+    if (rows_valid > 0 && !GSR_ABL(dbg, 8)) {
+        const float v_rgb[3] = {o_rgb[0], o_rgb[1], o_rgb[2]}, v_cl[3] = {o_cl[0], o_cl[1], o_cl[2]};
+        wave_store_rows<3>(rgb + 3 * wave_row0, stage, lane, rows_valid, v_rgb);
+        wave_store_rows<3>(clamped_state + 3 * wave_row0, stage + 256, lane, rows_valid, v_cl);
+        wave_store_rows<6>(cov3Ds + 6 * wave_row0, stage + 512, lane, rows_valid, o_cov);
+        const float inv_depth = visible ? 1.0f / o_depth : 0.0f;
+        const float v_rec[16] = {o_xy[0], o_xy[1], o_con[0], o_con[1], o_con[2], o_con[3], o_rgb[0], o_rgb[1], o_rgb[2], inv_depth, 0.0f, 0.0f,
+                                 0.0f, 0.0f, 0.0f, 0.0f};
+        wave_store_rows<16>(reinterpret_cast<float *>(rec + wave_row0), stage + 1024, lane, rows_valid, v_rec);
+    }
     if (!in_range) return;
     if (GSR_ABL(dbg, 8)) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
-
     radii[i] = o_radius;
     tiles_touched[i] = o_tiles;
     *reinterpret_cast<float2 *>(xy + 2 * i) = make_float2(o_xy[0], o_xy[1]);
     depths[i] = o_depth;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<float2 *>(cov3Ds + 6 * i + 2 * k) = make_float2(o_cov[2 * k], o_cov[2 * k + 1]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { rgb[3 * i + k] = o_rgb[k]; clamped_state[3 * i + k] = o_cl[k]; }
     *reinterpret_cast<float4 *>(conic_opacity + 4 * i) = make_float4(o_con[0], o_con[1], o_con[2], o_con[3]);
     }
 
     // internal products
-    float4 *rp = reinterpret_cast<float4 *>(rec + i);
-    const float inv_depth = visible ? 1.0f / o_depth : 0.0f;
-    rp[0] = make_float4(o_xy[0], o_xy[1], o_con[0], o_con[1]);
-    rp[1] = make_float4(o_con[2], o_con[3], o_rgb[0], o_rgb[1]);
-    rp[2] = make_float4(o_rgb[2], inv_depth, 0.0f, 0.0f);
     rect[i] = o_rect;
     const uint32_t dbits = visible ? __float_as_uint(o_depth) : 0xFFFFFFFFu;
     depth_item[i] = ((uint64_t)dbits << 32) | (uint64_t)(uint32_t)i;

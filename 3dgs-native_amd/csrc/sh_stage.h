@@ -66,3 +66,68 @@ __device__ __forceinline__ void sh_rows_store(float4 *__restrict__ g4, const flo
         if (r < rows_valid) g4[i] = lds_wave[r * SH_ROW_F4 + c];
     }
 }
+
+// Lanes of ONE wave handing data to each other through LDS need no s_barrier -- a wave's LDS operations execute in order --
+// but the COMPILER reasons per thread: to it, "lane 5 writes, lane 40 reads" is a data race it may reorder across (seen in
+// round 2: two consecutive wave_store_vec3_in_pad calls, the second call's stores of lanes 48-63 hoisted above the first
+// call's loads, which only lanes 0-47 execute).  This is the fence for that: no instruction, just no motion of memory
+// operations across it.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- wave-cooperative AoS stores -------------------------------------------------------------------------------------
+// A lane that stores its own K-float row (K = 3, 6, 16 ...) with K scalar / vector stores makes every store instruction
+// touch 64 different rows: partial 64-byte lines, K times over.  Instead the wave parks its 64 rows in LDS and streams the
+// 64*K contiguous floats out as whole float4s (one 1-KiB fully coalesced instruction per 256 floats).  `lds` is the wave's
+// own scratch (>= 64*K floats, 16-byte aligned; the dead SH image serves); `g` is the wave's first row in global memory
+// (16-byte aligned because the wave starts on a multiple of 64 rows); rows_valid < 64 only in the array's last wave, where a
+// trailing partial float4 is written float by float.  Row stride in LDS is K floats: for odd K (3) that is conflict-free,
+// for K = 6 two-way, negligible next to the global-memory side.
+template <int K>
+__device__ __forceinline__ void wave_store_rows(float *__restrict__ g, float *lds, int lane, int rows_valid, const float (&v)[K])
+{
+    wave_lds_fence(); // whatever the wave last read from this scratch has been read
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[lane * K + k] = v[k];
+    wave_lds_fence();
+    const int nfl = rows_valid * K; // floats to write
+    constexpr int NF4 = 64 * K / 4;
+#pragma unroll
+    for (int j0 = 0; j0 < NF4; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < NF4) {
+            if (4 * j + 3 < nfl) reinterpret_cast<float4 *>(g)[j] = reinterpret_cast<const float4 *>(lds)[j];
+            else
+                for (int e = 4 * j; e < nfl && e < 4 * j + 4; ++e) g[e] = lds[e];
+        }
+    }
+}
+
+// The same for 3-float rows when the wave's LDS image is still live (geom_bwd.hip keeps the SH rows, then their gradients,
+// in it until the kernel ends): the image's rows are padded from 12 to 13 float4, and that 13th float4 of a lane's own row
+// holds its 3 floats.  Output float4 j = floats 4j .. 4j+3 of the contiguous [64][3] block = pad slots of rows (4j)/3 ...
+__device__ __forceinline__ void wave_store_vec3_in_pad(float *__restrict__ g, float4 *lds_wave, int lane, int rows_valid, float x, float y, float z)
+{
+    float *img = reinterpret_cast<float *>(lds_wave);
+    float *mine = img + lane * (SH_ROW_F4 * 4) + 48;
+    wave_lds_fence(); // the previous call's reads of the pad slots are done
+    mine[0] = x; mine[1] = y; mine[2] = z;
+    wave_lds_fence();
+    const int nfl = rows_valid * 3;
+    if (lane < 48) {
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = 4 * lane + c;
+            o[c] = img[(e / 3) * (SH_ROW_F4 * 4) + 48 + (e % 3)];
+        }
+        if (4 * lane + 3 < nfl) reinterpret_cast<float4 *>(g)[lane] = make_float4(o[0], o[1], o[2], o[3]);
+        else
+            for (int c = 0; c < 4; ++c)
+                if (4 * lane + c < nfl) g[4 * lane + c] = o[c];
+    }
+}
