@@ -44,6 +44,7 @@ int tile_bits(int tiles)
 struct BinWs {
     int32_t *hist;       // [256 * nb]
     int32_t *totals;     // [256]
+    int32_t *edge;       // [3 * 256 * nb] first tile / last tile / position of every (digit, block) run of the last pass
     uint64_t *tile_a;    // [D]
     uint64_t *tile_b;    // [D]
     size_t bytes;
@@ -55,6 +56,7 @@ BinWs carve_bin(void *base, int64_t N, int64_t D)
     (void)N;
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(D) + 1));
     w.totals = c.take<int32_t>(256);
+    w.edge = c.take<int32_t>(3 * 256 * ((size_t)gsr_radix_blocks(D) + 1));
     w.tile_a = c.take<uint64_t>((size_t)D);
     w.tile_b = c.take<uint64_t>((size_t)D);
     w.bytes = c.off + 256;
@@ -414,14 +416,19 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     const int npass = (tb + 7) / 8;
     for (int pass = 0, shift = 0; pass < npass; ++pass) {
         const int bits = std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass));
-        HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, id_shift + shift, bits, item_bytes, s));
+        if (pass + 1 < npass) {
+            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, id_shift + shift, bits, item_bytes, s));
+        } else {
+            // 5. the last pass writes point_list and the tile ranges itself (reference forward.py:806-824, :561-586) instead of
+            //    sorted items that a further kernel would re-read
+            HIP_TRY(gsr_launch_radix_final_pass(tsrc, bw.hist, bw.totals, D, id_shift + shift, bits, item_bytes, id_shift, binning->point_list,
+                                                binning->ranges, bw.edge, s));
+        }
         shift += bits;
         void *t = tsrc; tsrc = tdst; tdst = t;
     }
     mark(st, 7, s);
-    // 5. point_list + ranges
-    HIP_TRY(gsr_launch_ranges(tsrc, binning->point_list, binning->ranges, D, id_shift, item_bytes, s));
-    mark(st, 8, s);
+    mark(st, 8, s); // (stage slot "ranges": nothing left in it)
     // 6. blend
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, s));
     mark(st, 9, s);

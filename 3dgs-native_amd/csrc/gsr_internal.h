@@ -66,14 +66,17 @@ static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_
 hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[radix*nb]*/, int32_t *totals /*[radix]*/,
                                  int64_t n, int shift, int bits, int item_bytes, hipStream_t s);
 
+// Last pass of the tile partition: writes point_list and ranges instead of the sorted items (scan_sort.hip, ScatterFinal).
+// `edge`: 3 * 256 * (gsr_radix_blocks(n) + 1) int32 of scratch.
+hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, int item_bytes,
+                                       int id_shift, int32_t *point_list, int32_t *ranges /* pre-zeroed */, int32_t *edge, hipStream_t s);
+
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
 hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
                                       const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s);
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
                              hipStream_t s);
-hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift,
-                             int item_bytes, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                     const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */, hipStream_t s);
 

@@ -200,10 +200,25 @@ struct ScatterCarry {
     int32_t *cnt_sorted;    // [n] (x1-x0)*(y1-y0) in output order
 };
 
-template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false>
+// FINAL (last pass of the tile partition only): the pass's output IS the sorted list, so instead of the items it writes what
+// the reference's last two steps produce from them (forward.py:806-824 un-padding copies, :561-586 wp_identify_tile_ranges):
+// the Gaussian ids go straight to point_list, and tile boundaries are written to `ranges` wherever both neighbours are in
+// sight -- inside a block's run of one digit, which is contiguous in the output.  The first and last tile of every run go
+// to an edge table [RADIX][nb] (a run's predecessor in the output is the previous non-empty run of the same digit, written
+// by another workgroup), which ranges_fixup_kernel resolves.  This replaces a kernel that re-read all D items.
+struct ScatterFinal {
+    int32_t *point_list;  // [n]
+    int32_t *ranges;      // [tiles * 2], pre-zeroed
+    int32_t *edge_first;  // [RADIX * nb] tile of the run's first item, -1 for an empty run
+    int32_t *edge_last;   // [RADIX * nb] tile of the run's last item
+    int32_t *edge_pos;    // [RADIX * nb] output position of the run's first item
+    int id_shift;
+};
+
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
-                                                            int64_t n, int shift, int nb, ScatterCarry carry)
+                                                            int64_t n, int shift, int nb, ScatterCarry carry, ScatterFinal fin)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
     __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
     __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
+    __shared__ int s_dcnt[FINAL ? RADIX : 1];      // FINAL: items of each digit in this block
     __shared__ int s_tmp[4];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -296,6 +312,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         if (own) {
             s_dstart[d] = inc - run;
             s_gbase[d] = tinc - td + hist[(size_t)d * nb + blockIdx.x];
+            if constexpr (FINAL) {
+                s_dcnt[d] = run;
+                if (run == 0) fin.edge_first[(size_t)d * nb + blockIdx.x] = -1;
+            }
         }
     }
     __syncthreads();
@@ -322,7 +342,25 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
             const ItemT it = s_items[slot];
             const int d = (int)((it >> shift) & (RADIX - 1));
             const int64_t pos = (int64_t)s_gbase[d] + (slot - s_dstart[d]);
-            out[pos] = it;
+            if constexpr (FINAL) {
+                const uint32_t tile = (uint32_t)(it >> fin.id_shift);
+                fin.point_list[pos] = (int32_t)(uint32_t)(it & (((ItemT)1 << fin.id_shift) - 1));
+                const int rel = slot - s_dstart[d];
+                const size_t e = (size_t)d * nb + blockIdx.x;
+                if (rel > 0) {
+                    const uint32_t prev = (uint32_t)(s_items[slot - 1] >> fin.id_shift);
+                    if (prev != tile) {
+                        fin.ranges[2 * prev + 1] = (int32_t)pos;
+                        fin.ranges[2 * tile] = (int32_t)pos;
+                    }
+                } else {
+                    fin.edge_first[e] = (int32_t)tile;
+                    fin.edge_pos[e] = (int32_t)pos;
+                }
+                if (rel == s_dcnt[d] - 1) fin.edge_last[e] = (int32_t)tile;
+            } else {
+                out[pos] = it;
+            }
             if constexpr (CARRY) {
                 const unsigned long long q = s_rect[slot]; // TileRect {x0, y0, x1, y1}, 16 bits each, little endian
                 reinterpret_cast<unsigned long long *>(carry.rect_sorted)[pos] = q;
@@ -331,6 +369,64 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
             }
         }
     }
+}
+
+// One 1024-thread workgroup per digit: joins consecutive non-empty runs of the digit (ScatterFinal's edge table).  Between
+// two digits the tile always changes (the digit is the top bits of the tile id), so a digit's first run always opens a
+// range at the digit's first position and its last run closes one at the digit's end; inside the digit a range boundary
+// sits wherever a run's first tile differs from the previous non-empty run's last tile.
+__global__ __launch_bounds__(1024) void ranges_fixup_kernel(const int32_t *__restrict__ edge_first, const int32_t *__restrict__ edge_last,
+                                                            const int32_t *__restrict__ edge_pos, const int32_t *__restrict__ totals, int nb,
+                                                            int radix, int32_t *__restrict__ ranges)
+{
+    __shared__ int s_last[16]; // per wave: last tile of its last non-empty run, -1 if it has none
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int total = totals[d];
+    if (total == 0) return;
+    int digit_start = 0;
+    for (int k = lane; k < d; k += 64) digit_start += totals[k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) digit_start += __shfl_xor(digit_start, o, 64);
+    const size_t row = (size_t)d * nb;
+    // each wave owns a contiguous slice of the digit's nb runs
+    const int per = (nb + 15) / 16;
+    const int b0 = wv * per, b1 = min(nb, b0 + per);
+    // pass 1: this wave's last non-empty run
+    int my_last = -1;
+    for (int base = b0; base < b1; base += 64) {
+        const int b = base + lane;
+        const bool ne = b < b1 && edge_first[row + b] >= 0;
+        const unsigned long long m = __ballot(ne);
+        if (m) {
+            const int hi = 63 - __builtin_clzll(m);
+            my_last = __shfl(ne ? edge_last[row + b] : -1, hi, 64);
+        }
+    }
+    if (lane == 0) s_last[wv] = my_last;
+    __syncthreads();
+    int carry = -1; // last tile of the nearest non-empty run before this wave's slice
+    for (int k = wv - 1; k >= 0; --k)
+        if (s_last[k] >= 0) { carry = s_last[k]; break; }
+    // pass 2: boundaries
+    for (int base = b0; base < b1; base += 64) {
+        const int b = base + lane;
+        const bool ne = b < b1 && edge_first[row + b] >= 0;
+        const int first = ne ? edge_first[row + b] : -1, last = ne ? edge_last[row + b] : -1, pos = ne ? edge_pos[row + b] : 0;
+        const unsigned long long m = __ballot(ne);
+        const unsigned long long below = m & (lane == 0 ? 0ull : (~0ull >> (64 - lane)));
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        const int prev_in_chunk = __shfl(last, src, 64);
+        const int prev = below ? prev_in_chunk : carry;
+        if (ne) {
+            if (prev < 0) ranges[2 * first] = pos;                 // the digit's first run: pos == digit_start
+            else if (prev != first) { ranges[2 * prev + 1] = pos; ranges[2 * first] = pos; }
+        }
+        if (m) carry = __shfl(last, 63 - __builtin_clzll(m), 64);
+    }
+    // the digit's last run closes its range at the digit's end
+    bool later = false;
+    for (int k = wv + 1; k < 16; ++k) later = later || s_last[k] >= 0;
+    if (!later && my_last >= 0 && lane == 0) ranges[2 * my_last + 1] = digit_start + total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -392,27 +488,6 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     }
 }
 
-// sorted tile items -> point_list + tile ranges (reference forward.py:561-586); ranges pre-zeroed
-template <typename ItemT>
-__global__ __launch_bounds__(256) void ranges_kernel(const ItemT *__restrict__ items, int32_t *__restrict__ point_list,
-                                                     int32_t *__restrict__ ranges, int64_t D, int id_shift)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= D) return;
-    const ItemT it = items[idx];
-    point_list[idx] = (int32_t)(uint32_t)(it & (((ItemT)1 << id_shift) - 1));
-    const uint32_t cur = (uint32_t)(it >> id_shift);
-    if (idx == 0) ranges[2 * cur] = 0;
-    else {
-        const uint32_t prev = (uint32_t)(items[idx - 1] >> id_shift);
-        if (cur != prev) {
-            ranges[2 * prev + 1] = (int32_t)idx;
-            ranges[2 * cur] = (int32_t)idx;
-        }
-    }
-    if (idx == D - 1) ranges[2 * cur + 1] = (int32_t)D;
-}
-
 } // namespace
 
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
@@ -442,12 +517,12 @@ static void radix_pass_bits(const ItemT *in, ItemT *out, int32_t *hist, int32_t 
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{});
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{}, ScatterFinal{});
     } else {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{});
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{}, ScatterFinal{});
     }
 }
 
@@ -476,6 +551,53 @@ hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32
     return radix_pass_any<uint64_t>((const uint64_t *)in, (uint64_t *)out, hist, totals, n, shift, bits, s);
 }
 
+// The LAST pass of the tile partition: histogram, row scan, then a scatter that writes point_list and the in-sight range
+// boundaries directly (ScatterFinal), and the edge fix-up.  `edge` holds 3 * (1 << bits) * nb int32 (gsr_radix_blocks(n) = nb).
+template <int BITS, typename ItemT>
+static void radix_final_bits(const ItemT *in, int32_t *hist, int32_t *totals, int64_t n, int shift, const ScatterFinal &fin, hipStream_t s)
+{
+    constexpr int RADIX = 1 << BITS;
+    if (n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64)) {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, false, true>), dim3(nb), dim3(256), 0, s, in, (ItemT *)nullptr,
+                           hist, totals, n, shift, nb, ScatterCarry{}, fin);
+        hipLaunchKernelGGL(ranges_fixup_kernel, dim3(RADIX), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, totals, nb, RADIX, fin.ranges);
+    } else {
+        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, false, true>), dim3(nb), dim3(256), 0, s, in, (ItemT *)nullptr, hist,
+                           totals, n, shift, nb, ScatterCarry{}, fin);
+        hipLaunchKernelGGL(ranges_fixup_kernel, dim3(RADIX), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, totals, nb, RADIX, fin.ranges);
+    }
+}
+
+template <typename ItemT>
+static hipError_t radix_final_any(const ItemT *in, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, const ScatterFinal &fin, hipStream_t s)
+{
+    switch (bits) {
+    case 4: radix_final_bits<4, ItemT>(in, hist, totals, n, shift, fin, s); break;
+    case 5: radix_final_bits<5, ItemT>(in, hist, totals, n, shift, fin, s); break;
+    case 6: radix_final_bits<6, ItemT>(in, hist, totals, n, shift, fin, s); break;
+    case 7: radix_final_bits<7, ItemT>(in, hist, totals, n, shift, fin, s); break;
+    case 8: radix_final_bits<8, ItemT>(in, hist, totals, n, shift, fin, s); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, int item_bytes,
+                                       int id_shift, int32_t *point_list, int32_t *ranges, int32_t *edge, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t per = ((size_t)1 << bits) * (size_t)gsr_radix_blocks(n);
+    const ScatterFinal fin{point_list, ranges, edge, edge + per, edge + 2 * per, id_shift};
+    if (item_bytes == 4) return radix_final_any<uint32_t>((const uint32_t *)in, hist, totals, n, shift, bits, fin, s);
+    return radix_final_any<uint64_t>((const uint64_t *)in, hist, totals, n, shift, bits, fin, s);
+}
+
 // The last pass of the depth sort (8-bit digit of 64-bit items) with the rectangle carry.
 hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
                                       const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s)
@@ -486,12 +608,12 @@ hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t
         const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry, ScatterFinal{});
     } else {
         const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry, ScatterFinal{});
     }
     return hipGetLastError();
 }
@@ -505,17 +627,5 @@ hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *
         hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n);
     else
         hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n);
-    return hipGetLastError();
-}
-
-hipError_t gsr_launch_ranges(const void *sorted_tile_items, int32_t *point_list, int32_t *ranges, int64_t D, int id_shift, int item_bytes,
-                             hipStream_t s)
-{
-    if (D <= 0) return hipSuccess;
-    const dim3 grid((unsigned)gsr_div_up(D, 256));
-    if (item_bytes == 4)
-        hipLaunchKernelGGL(ranges_kernel<uint32_t>, grid, dim3(256), 0, s, (const uint32_t *)sorted_tile_items, point_list, ranges, D, id_shift);
-    else
-        hipLaunchKernelGGL(ranges_kernel<uint64_t>, grid, dim3(256), 0, s, (const uint64_t *)sorted_tile_items, point_list, ranges, D, id_shift);
     return hipGetLastError();
 }
