@@ -81,6 +81,30 @@ __device__ __forceinline__ float wave_scan_add(float v)
         : "+v"(v));
     return v;
 }
+// The same scans over each 32-lane half of the wave separately (lanes 0-31 and 32-63 hold different pixels): without the
+// last, row_bcast:31 step; row_bcast:15 with row mask 0xa feeds rows 1 and 3 from rows 0 and 2.
+__device__ __forceinline__ float half_scan_mul(float v)
+{
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float half_scan_add(float v)
+{
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ int wave_max_i(int v)
 {
 #pragma unroll
@@ -225,8 +249,12 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
 
         // ---- one bucket: lane k takes the k-th queued entry (still deepest first) ----
         const int n = min(64, qn);
-        const bool valid = lane < n;
-        const int slot = (head + lane) & (QCAP - 1);
+        // A bucket of at most 32 entries (every block's last one, half of the time) runs TWO pixels per step: lanes 0-31 hold
+        // the entries against pixel 2s, lanes 32-63 the same entries against pixel 2s + 1, and the scans stay inside each half.
+        const bool two = n <= 32 && (NPIX % 2 == 0);
+        const int elane = two ? (lane & 31) : lane; // which entry of the bucket this lane holds
+        const bool valid = elane < n;
+        const int slot = (head + elane) & (QCAP - 1);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         float colb = 0.0f;
         int idx = 0x7FFFFFFF, id = 0;
@@ -255,41 +283,64 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, S1 = 0.f, S2 = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sop = 0.f;
         bool touched = false;
 
-        for (int q = 0; q < (GSR_ABL(dbg, 2) ? 1 : NPIX); ++q) {
-            const float4 pb = s_pb[q];
-            const int pkept = __float_as_int(pb.w);
-            if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
-            TL_COUNT(7, 1ull)
-            const float4 pa = s_pa[q];
-            const float2 carry = s_carry[q];
-            const float d_x = a.x - pa.x, d_y = a.y - pa.y;
-            const float power = power_ref_order(a.z, a.w, b.x, d_x, d_y);
-            const float G = fast_exp(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-            const float inv = fast_rcp(1.0f - alpha);    // 1/(1-alpha): scanned as a product, and reused in dL/dalpha
-            const float m = live ? inv : 1.0f;
-            const float Pi = wave_scan_mul(m);
-            const float rdenom = carry.x * Pi;          // product of 1/(1-alpha) over this entry and everything deeper
-            const float T = pa.z * rdenom;              // transmittance in front of this entry = T_final / prod(1-alpha)
-            const float cd = b.z * pb.x + b.w * pb.y + colb * pb.z;
-            const float w = alpha * T;
-            const float qv = live ? w * cd : 0.0f;
-            const float Qi = wave_scan_add(qv);
-            if (lane == 63) s_carry[q] = make_float2(rdenom, carry.y + Qi);
-            if (live) {
-                touched = true;
-                const float Qe = carry.y + (Qi - qv);   // deeper entries only
-                const float dL_dalpha = T * cd - (Qe + pa.w) * inv;
-                g_c0 += w * pb.x; g_c1 += w * pb.y; g_c2 += w * pb.z;
-                const float gd = G * dL_dalpha;
-                Sop += gd;
-                const float h = b.y * gd;                // dL/dG * G = o * dL/dalpha * G
-                const float hx = h * d_x, hy = h * d_y;
-                S1 += hx; S2 += hy;
-                Sxx += hx * d_x; Sxy += hx * d_y; Syy += hy * d_y;
+#define GSR_PIXEL_STEP(Q, SCAN_MUL, SCAN_ADD, CARRY_LANE)                                                                      \
+    {                                                                                                                         \
+        const float4 pa = s_pa[Q];                                                                                            \
+        const float2 carry = s_carry[Q];                                                                                      \
+        const float d_x = a.x - pa.x, d_y = a.y - pa.y;                                                                       \
+        const float power = power_ref_order(a.z, a.w, b.x, d_x, d_y);                                                         \
+        const float G = fast_exp(power);                                                                                      \
+        const float alpha = fminf(0.99f, b.y * G);                                                                            \
+        const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));                                      \
+        const float inv = fast_rcp(1.0f - alpha); /* 1/(1-alpha): scanned as a product, and reused in dL/dalpha */            \
+        const float m = live ? inv : 1.0f;                                                                                    \
+        const float Pi = SCAN_MUL(m);                                                                                         \
+        const float rdenom = carry.x * Pi; /* product of 1/(1-alpha) over this entry and everything deeper */                 \
+        const float T = pa.z * rdenom;     /* transmittance in front of this entry = T_final / prod(1-alpha) */               \
+        const float cd = b.z * pb.x + b.w * pb.y + colb * pb.z;                                                               \
+        const float w = alpha * T;                                                                                            \
+        const float qv = live ? w * cd : 0.0f;                                                                                \
+        const float Qi = SCAN_ADD(qv);                                                                                        \
+        if (CARRY_LANE) s_carry[Q] = make_float2(rdenom, carry.y + Qi);                                                       \
+        if (live) {                                                                                                           \
+            touched = true;                                                                                                   \
+            const float Qe = carry.y + (Qi - qv); /* deeper entries only */                                                   \
+            const float dL_dalpha = T * cd - (Qe + pa.w) * inv;                                                               \
+            g_c0 += w * pb.x; g_c1 += w * pb.y; g_c2 += w * pb.z;                                                             \
+            const float gd = G * dL_dalpha;                                                                                   \
+            Sop += gd;                                                                                                        \
+            const float h = b.y * gd; /* dL/dG * G = o * dL/dalpha * G */                                                     \
+            const float hx = h * d_x, hy = h * d_y;                                                                           \
+            S1 += hx; S2 += hy;                                                                                               \
+            Sxx += hx * d_x; Sxy += hx * d_y; Syy += hy * d_y;                                                                \
+        }                                                                                                                     \
+    }
+        if (!two) {
+            for (int q = 0; q < (GSR_ABL(dbg, 2) ? 1 : NPIX); ++q) {
+                const float4 pb = s_pb[q];
+                const int pkept = __float_as_int(pb.w);
+                if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
+                TL_COUNT(7, 1ull)
+                GSR_PIXEL_STEP(q, wave_scan_mul, wave_scan_add, lane == 63)
             }
+        } else {
+            const int sub = lane >> 5;
+            for (int q2 = 0; q2 < (GSR_ABL(dbg, 2) ? 2 : NPIX); q2 += 2) {
+                const int q = q2 + sub;
+                const float4 pb = s_pb[q];
+                const int pkept = __float_as_int(pb.w);
+                TL_COUNT(7, 1ull)
+                GSR_PIXEL_STEP(q, half_scan_mul, half_scan_add, (lane & 31) == 31)
+            }
+            // an entry's sums are split over its two lanes: add the halves (lanes 32-63 then hold copies and stay out of the flush)
+            g_c0 += __shfl_xor(g_c0, 32, 64); g_c1 += __shfl_xor(g_c1, 32, 64); g_c2 += __shfl_xor(g_c2, 32, 64);
+            S1 += __shfl_xor(S1, 32, 64); S2 += __shfl_xor(S2, 32, 64);
+            Sxx += __shfl_xor(Sxx, 32, 64); Sxy += __shfl_xor(Sxy, 32, 64); Syy += __shfl_xor(Syy, 32, 64);
+            Sop += __shfl_xor(Sop, 32, 64);
+            const int partner_touched = __shfl_xor((int)touched, 32, 64); // unconditionally: a cross-lane read must not sit behind ||
+            touched = (touched || partner_touched != 0) && lane < 32;
         }
+#undef GSR_PIXEL_STEP
         TL(3) // pixel loop
         // dL/dmean2D = dL/dG * dG/ddel * 0.5*(W,H), dG/ddelx = -G (a dx + b dy); dL/dconic = -0.5 h (dx^2, dx dy, dy^2)
         const float g_mx = -(a.z * S1 + a.w * S2) * ddelx_dx;
