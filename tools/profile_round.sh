@@ -33,4 +33,9 @@ python tools/summarize_pmc.py $label C3 $(find $out/fetch -name '*counter_collec
 cp profiles/sq_counters.json $out/summary/ 2>/dev/null || true
 python tools/summarize_sq.py $label C3 $out/summary $(find $out/sq1 $out/sq2 $out/sq3 -name '*counter_collection.csv')
 rm -rf $out/kt $out/fetch $out/write $out/sq1 $out/sq2 $out/sq3      # keep the merge small: the summaries are what gets committed
+# the counters now on file belong to this build: run the default bench once more so its line carries roofline.traffic and
+# roofline_valu (bench.py quotes them only for the build they were measured on)
+cp $out/summary/pmc_traffic.json $out/summary/sq_counters.json profiles/
+timeout -k 10 400 python bench.py > $out/${label}_bench_line.json 2>> $out/bench.err
+tail -c 900 $out/${label}_bench_line.json; echo
 head -8 $out/${label}_kernel_stats_bench_steps10.csv | cut -c1-160
