@@ -74,8 +74,8 @@ def stage_bytes(N, Nv, D, P, Tn):
         "depth_sort": 4 * 24 * N,             # 4 passes x (8 B histogram read + 8 B read + 8 B write) per item
         "depth_scan": 16 * N,
         "expand": 20 * Nv + 8 * D,
-        "tile_sort": 2 * 24 * D,
-        "ranges": 12 * D + 8 * Tn,
+        "tile_sort": 2 * 24 * D + 12 * D + 8 * Tn,   # since round 2 the last pass also writes point_list and ranges (the old "ranges" stage)
+        "ranges": 0,
         "blend_fwd": 44 * D + 8 * Tn + 24 * P,
         "bwd_prep": 64 * N,
         "blend_bwd": 40 * D + 20 * P + 44 * N,

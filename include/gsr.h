@@ -298,8 +298,8 @@ enum {
     GSR_ST_DEPTH_SCAN,     /* depth-order offsets: exclusive scan of the carried counts */
     GSR_ST_HOST_GAP,       /* stream idle between gsr_forward_count and gsr_forward_render (host round trip) */
     GSR_ST_EXPAND,         /* (tile,id) item expansion */
-    GSR_ST_TILE_SORT,      /* radix passes over D items */
-    GSR_ST_RANGES,         /* point_list + ranges */
+    GSR_ST_TILE_SORT,      /* radix passes over D items; the last one writes point_list and ranges */
+    GSR_ST_RANGES,         /* (empty since the last tile pass took this work over; slot kept so stage indices stay stable) */
     GSR_ST_BLEND_FWD,      /* blend_forward_kernel */
     GSR_ST_BWD_PREP,       /* accumulator memset + record packing */
     GSR_ST_BLEND_BWD,      /* blend_backward_kernel */
