@@ -216,56 +216,39 @@ struct CountNote {
     const void *ws;
     int64_t N, D;
     uint64_t stamp;
-    Readback *sort_rb; // pinned word + event: the sample sort's overflow flag, valid once the event has passed; nullptr = nothing to check
 };
 std::mutex g_note_mu;
 std::vector<CountNote> g_notes;
 uint64_t g_note_clock = 0;
 constexpr size_t MAX_NOTES = 256;
-void readback_release(Readback *r)
-{
-    if (!r) return;
-    std::lock_guard<std::mutex> lk(g_rb_mu);
-    r->busy = false;
-}
-void note_count(const void *ws, int64_t N, int64_t D, Readback *sort_rb)
+void note_count(const void *ws, int64_t N, int64_t D)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    Readback *stale = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_note_mu);
-        CountNote *slot = nullptr;
-        for (CountNote &c : g_notes)
-            if (c.dev == dev && c.ws == ws) slot = &c;
-        if (!slot) {
-            if (g_notes.size() < MAX_NOTES) {
-                g_notes.push_back(CountNote{});
-                slot = &g_notes.back();
-            } else {
-                slot = &*std::min_element(g_notes.begin(), g_notes.end(), [](const CountNote &a, const CountNote &b) { return a.stamp < b.stamp; });
-            }
+    std::lock_guard<std::mutex> lk(g_note_mu);
+    CountNote *slot = nullptr;
+    for (CountNote &c : g_notes)
+        if (c.dev == dev && c.ws == ws) slot = &c;
+    if (!slot) {
+        if (g_notes.size() < MAX_NOTES) {
+            g_notes.push_back(CountNote{});
+            slot = &g_notes.back();
+        } else {
+            slot = &*std::min_element(g_notes.begin(), g_notes.end(), [](const CountNote &a, const CountNote &b) { return a.stamp < b.stamp; });
         }
-        stale = slot->sort_rb; // a count that was never rendered
-        *slot = CountNote{dev, ws, N, D, ++g_note_clock, sort_rb};
     }
-    readback_release(stale);
+    *slot = CountNote{dev, ws, N, D, ++g_note_clock};
 }
-// 1 = matches, 0 = mismatch, -1 = this workspace has no recorded count.  On a match *sort_rb receives the pending overflow
-// check (or nullptr) and the note forgets it: the caller checks and releases it.
-int check_count(const void *ws, int64_t N, int64_t D, Readback **sort_rb)
+// 1 = matches, 0 = mismatch, -1 = this workspace has no recorded count
+int check_count(const void *ws, int64_t N, int64_t D)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    *sort_rb = nullptr;
     std::lock_guard<std::mutex> lk(g_note_mu);
     for (CountNote &c : g_notes)
         if (c.dev == dev && c.ws == ws) {
             c.stamp = ++g_note_clock;
-            if (c.N != N || c.D != D) return 0;
-            *sort_rb = c.sort_rb;
-            c.sort_rb = nullptr;
-            return 1;
+            return (c.N == N && c.D == D) ? 1 : 0;
         }
     return -1;
 }
@@ -281,19 +264,6 @@ void read_tuning()
 
 } // namespace
 
-// The four-pass LSD radix sort of the N (depth bits << 32 | id) items (stable from id order, four 8-bit passes over the high
-// word, ending back in depth_item; the last one also carries each Gaussian's tile rectangle and tile count to its sorted
-// position).  Round 1's depth order; now the fallback of the sample sort and the GSR_DEBUG bit 7 path.
-static hipError_t lsd_depth_sort(const GeomWs &ws, int64_t N, hipStream_t s)
-{
-    uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
-    for (int pass = 0; pass < 3; ++pass) {
-        if (hipError_t e = gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, 8, s)) return e;
-        uint64_t *t = src; src = dst; dst = t;
-    }
-    return gsr_launch_depth_last_pass(src, dst, ws.hist, ws.totals, N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s);
-}
-
 GeomWs gsr_carve_geom(void *base, int64_t N)
 {
     Carver c(base);
@@ -308,11 +278,6 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
     w.totals = c.take<int32_t>(256);
-    w.do_split = c.take<uint64_t>(2048);
-    w.do_totals = c.take<int32_t>(2049);
-    w.do_cursor = c.take<int32_t>(2049);
-    w.do_flag = c.take<int32_t>(1);
-    w.do_bucket = c.take<uint16_t>((size_t)N);
     w.bytes = c.off + 256;
     return w;
 }
@@ -375,32 +340,26 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, s));
     mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
-    // Work that does not need D goes out before the host waits: the Gaussians in (depth bits, id) order -- stable by depth
-    // from id order -- with each one's tile rectangle and tile count carried to its sorted position, and the depth-order
-    // offsets (exclusive scan of those counts).  The order comes from a four-launch sample sort (depth_order.hip); GSR_DEBUG
-    // bit 7 selects the four-pass LSD radix sort it replaced, which is also what gsr_forward_render falls back on should the
-    // sample sort ever report a bucket that did not fit (its flag reaches the host with the depth-order scan, checked there).
-    Readback *sort_rb = nullptr;
-    if (!(gsr_debug_flags & 128)) {
-        sort_rb = readback_acquire();
-        if (!sort_rb) return GSR_E_HIP;
-        *sort_rb->pinned = 0;
-        if (gsr_launch_depth_order(ws, N, s) != hipSuccess) { readback_release(sort_rb); return GSR_E_HIP; }
-        mark(st, 3, s);
-        if (gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s, ws.do_flag, sort_rb->pinned) != hipSuccess ||
-            hipEventRecord(sort_rb->ev, s) != hipSuccess) { readback_release(sort_rb); return GSR_E_HIP; }
-        mark(st, 4, s);
-    } else {
-        HIP_TRY(lsd_depth_sort(ws, N, s));
+    // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id order, four 8-bit
+    // passes over the high word, ending back in depth_item; the last one also carries each Gaussian's tile rectangle and
+    // tile count to its sorted position) and the depth-order offsets (exclusive scan of those counts).
+    {
+        uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
+        for (int pass = 0; pass < 3; ++pass) {
+            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, 8, s));
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        // the last pass also carries each Gaussian's tile rectangle and tile count to its sorted position
+        HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.totals, N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
         mark(st, 3, s);
         HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s));
         mark(st, 4, s);
     }
-    if (hipEventSynchronize(rb->ev) != hipSuccess) { readback_release(sort_rb); return GSR_E_HIP; } // D is on the host; the GPU keeps sorting
+    HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting
     const int32_t last = *rb->pinned;
     *num_rendered = (int64_t)last;
-    if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) { readback_release(sort_rb); return GSR_E_OVERFLOW; }
-    note_count(geom_ws, N, (int64_t)last, sort_rb);
+    if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
+    note_count(geom_ws, N, (int64_t)last);
     return GSR_OK;
 }
 
@@ -434,23 +393,8 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     if (!geom_ws || geom_ws_bytes < gsr_geom_workspace_bytes(N)) return GSR_E_WORKSPACE;
     if (!bin_ws || bin_ws_bytes < gsr_binning_workspace_bytes(N, D, cam.W, cam.H)) return GSR_E_WORKSPACE;
     // D must be the count gsr_forward_count returned for the items now in geom_ws (see CountNote above)
-    Readback *sort_rb = nullptr;
-    if (check_count(geom_ws, N, D, &sort_rb) != 1) return GSR_E_CAPACITY;
+    if (check_count(geom_ws, N, D) != 1) return GSR_E_CAPACITY;
     const GeomWs gw = gsr_carve_geom(geom_ws, N);
-    if (sort_rb) {
-        // the sample sort's verdict is on the host by now (its event sits behind the depth-order scan that gsr_forward_count
-        // enqueued; normally long past).  A bucket that did not fit LDS means depth_item holds no valid order: redo it here
-        // with the LSD sort -- which needs the unsorted items back first -- and rescan.
-        const hipError_t e = hipEventSynchronize(sort_rb->ev);
-        const int32_t overflow = *sort_rb->pinned;
-        readback_release(sort_rb);
-        if (e != hipSuccess) return GSR_E_HIP;
-        if (overflow) {
-            HIP_TRY(gsr_launch_rebuild_depth_items(gw, *geom, N, s));
-            HIP_TRY(lsd_depth_sort(gw, N, s));
-            HIP_TRY(gsr_launch_scan(gw.cnt_sorted, nullptr, gw.doff, gw.scan_tmp, N, 2, nullptr, s));
-        }
-    }
     const BinWs bw = carve_bin(bin_ws, N, D);
 
     const int st = t_fwd_record;

@@ -45,12 +45,6 @@ struct GeomWs {
     int32_t *scan_tmp;    // block sums for the scans
     int32_t *hist;        // [256 * nb(N)] radix block histograms
     int32_t *totals;      // [256]
-    // sample-sort scratch (depth_order.hip)
-    uint64_t *do_split;   // [2048] splitters
-    int32_t *do_totals;   // [2049] items per bucket
-    int32_t *do_cursor;   // [2049] scatter cursors
-    int32_t *do_flag;     // [1] a bucket did not fit LDS: the order in depth_item is NOT valid, redo with the LSD sort
-    uint16_t *do_bucket;  // [N] bucket of every item
     size_t bytes;
 };
 GeomWs gsr_carve_geom(void *base, int64_t N);
@@ -62,13 +56,7 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 // mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
-                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s,
-                           const int32_t *word_src = nullptr, int32_t *word_dst = nullptr /* optional: *word_dst = *word_src */);
-
-// The Gaussians in (depth bits, id) order by sample sort (depth_order.hip): depth_item sorted in place (through sort_tmp),
-// rect_sorted / cnt_sorted carried along; *ws.do_flag != 0 afterwards means "not done, use the LSD passes".
-hipError_t gsr_launch_depth_order(const GeomWs &ws, int64_t N, hipStream_t s);
-hipError_t gsr_launch_rebuild_depth_items(const GeomWs &ws, const GsrGeom &g, int64_t N, hipStream_t s); // depth_item as preprocess left it
+                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s);
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096
@@ -105,16 +93,15 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
-// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks, bit 7 the LSD radix
-// depth sort instead of the sample sort, bit 8 a 16-item bucket capacity in the sample sort (so it overflows and the host
-// redoes the order with the LSD sort) -- same results by other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
+// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks -- same results by
+// other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
 // one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->
 // libgsr_hip_ablate.so, -DGSR_ABLATE, used by tools/stage_bench.sh) and are compiled out of libgsr_hip.so.
 #ifdef GSR_ABLATE
-#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128 | 256)
+#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64)
 #define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
 #else
-#define GSR_DEBUG_ALLOWED (32 | 64 | 128 | 256)
+#define GSR_DEBUG_ALLOWED (32 | 64)
 #define GSR_ABL(flags, bit) false
 #endif
 extern int gsr_debug_flags;

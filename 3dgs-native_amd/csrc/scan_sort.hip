@@ -87,8 +87,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 
 template <int MODE>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
-                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out,
-                                                         const int32_t *__restrict__ word_src, int32_t *word_dst)
+                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -123,9 +122,6 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
     }
     // the grand total goes straight to a (pinned, device-visible) host word: no separate copy kernel for D
     if (total_out && base + SCAN_WAVE_ITEMS >= n && ((n - 1 - base) & 63) == lane) *total_out = total;
-    // ... and so does one more device word the caller wants on the host at this point of the stream (the sample sort's
-    // overflow flag, api.hip)
-    if (word_dst && wid == 0 && lane == 0) *word_dst = *word_src;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -495,7 +491,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
 } // namespace
 
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
-                           int32_t *total_out, hipStream_t s, const int32_t *word_src, int32_t *word_dst)
+                           int32_t *total_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
@@ -503,10 +499,10 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     (void)items;
     if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out, word_src, word_dst);
+        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else if (mode == 2) {
         hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out, word_src, word_dst);
+        hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else {
         return hipErrorInvalidValue;
     }
