@@ -42,8 +42,8 @@ int tile_bits(int tiles)
 }
 
 struct BinWs {
-    int32_t *hist;       // [256 * nb]
-    int32_t *totals;     // [256]
+    int32_t *hist;       // [nb][256]
+    int32_t *acc[2];     // [gsr_radix_acc_ints(D)] each: see GeomWs::acc
     int32_t *edge;       // [3 * 256 * nb] first tile / last tile / position of every (digit, block) run of the last pass
     uint64_t *tile_a;    // [D]
     uint64_t *tile_b;    // [D]
@@ -55,7 +55,8 @@ BinWs carve_bin(void *base, int64_t N, int64_t D)
     BinWs w;
     (void)N;
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(D) + 1));
-    w.totals = c.take<int32_t>(256);
+    w.acc[0] = c.take<int32_t>(gsr_radix_acc_ints(D));
+    w.acc[1] = c.take<int32_t>(gsr_radix_acc_ints(D));
     w.edge = c.take<int32_t>(3 * 256 * ((size_t)gsr_radix_blocks(D) + 1));
     w.tile_a = c.take<uint64_t>((size_t)D);
     w.tile_b = c.take<uint64_t>((size_t)D);
@@ -277,7 +278,8 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.doff = c.take<int32_t>((size_t)N);
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
-    w.totals = c.take<int32_t>(256);
+    w.acc[0] = c.take<int32_t>(gsr_radix_acc_ints(N));
+    w.acc[1] = c.take<int32_t>(gsr_radix_acc_ints(N));
     w.bytes = c.off + 256;
     return w;
 }
@@ -346,11 +348,12 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     {
         uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
         for (int pass = 0; pass < 3; ++pass) {
-            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.totals, N, 32 + 8 * pass, 8, 8, s));
+            // pass p accumulates into acc[p & 1] (cleared by preprocess for p = 0) and clears the other one for pass p + 1
+            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.acc[pass & 1], N, 32 + 8 * pass, 8, 8, ws.acc[(pass + 1) & 1], s));
             uint64_t *t = src; src = dst; dst = t;
         }
         // the last pass also carries each Gaussian's tile rectangle and tile count to its sorted position
-        HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.totals, N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
+        HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.acc[1], N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
         mark(st, 3, s);
         HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s));
         mark(st, 4, s);
@@ -408,7 +411,8 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     while ((1LL << id_bits) < N) ++id_bits;
     const bool narrow = tb + id_bits <= 32 && !(gsr_debug_flags & 32); // GSR_DEBUG bit 5: 64-bit tile items at any size (tests)
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
-    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, s));
+    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
+                              (int)gsr_radix_acc_ints(D), s));
     mark(st, 6, s);
     // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible
     //    (12 bits -> 6+6, 13 -> 7+6)
@@ -417,11 +421,11 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     for (int pass = 0, shift = 0; pass < npass; ++pass) {
         const int bits = std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass));
         if (pass + 1 < npass) {
-            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.totals, D, id_shift + shift, bits, item_bytes, s));
+            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, bw.acc[(pass + 1) & 1], s));
         } else {
             // 5. the last pass writes point_list and the tile ranges itself (reference forward.py:806-824, :561-586) instead of
             //    sorted items that a further kernel would re-read
-            HIP_TRY(gsr_launch_radix_final_pass(tsrc, bw.hist, bw.totals, D, id_shift + shift, bits, item_bytes, id_shift, binning->point_list,
+            HIP_TRY(gsr_launch_radix_final_pass(tsrc, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, id_shift, binning->point_list,
                                                 binning->ranges, bw.edge, s));
         }
         shift += bits;

@@ -43,8 +43,8 @@ struct GeomWs {
     int32_t *cnt_sorted;  // [N] tile counts in depth order (same pass)
     int32_t *doff;        // [N] exclusive tile-pair offsets in depth order
     int32_t *scan_tmp;    // block sums for the scans
-    int32_t *hist;        // [256 * nb(N)] radix block histograms
-    int32_t *totals;      // [256]
+    int32_t *hist;        // [nb(N)][256] radix block histograms
+    int32_t *acc[2];      // [gsr_radix_acc_ints(N)] each: digit + super-block totals of a pass; consecutive passes alternate
     size_t bytes;
 };
 GeomWs gsr_carve_geom(void *base, int64_t N);
@@ -63,20 +63,33 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
 #define GSR_RADIX_SMALL_CHUNK 1024      // chunk used when n <= GSR_RADIX_SMALL_N (more, smaller blocks)
 #define GSR_RADIX_SMALL_N (4 << 20)
 static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_N ? (n + GSR_RADIX_SMALL_CHUNK - 1) / GSR_RADIX_SMALL_CHUNK : (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
-hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[radix*nb]*/, int32_t *totals /*[radix]*/,
-                                 int64_t n, int shift, int bits, int item_bytes, hipStream_t s);
+// A pass's blocks are grouped into super-blocks of about sqrt(nb) blocks; its accumulators are 256 digit totals followed by
+// 256 per super-block (scan_sort.hip, radix_hist_kernel).
+static inline int gsr_radix_sb(int nb)
+{
+    int sb = 16;
+    while ((int64_t)sb * sb < nb) ++sb;
+    return sb;
+}
+static inline size_t gsr_radix_acc_ints(int64_t n)
+{
+    const int nb = (int)gsr_radix_blocks(n), sb = gsr_radix_sb(nb); // GSR_DEBUG bit 6 cuts n into fewer blocks: fewer rows
+    return 256 * (size_t)(3 + nb / sb);
+}
+hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[nb][radix]*/, int32_t *acc /* gsr_radix_acc_ints(n), zero */,
+                                 int64_t n, int shift, int bits, int item_bytes, int32_t *zero_acc /* next pass's, or NULL */, hipStream_t s);
 
 // Last pass of the tile partition: writes point_list and ranges instead of the sorted items (scan_sort.hip, ScatterFinal).
 // `edge`: 3 * 256 * (gsr_radix_blocks(n) + 1) int32 of scratch.
-hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, int item_bytes,
+hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
                                        int id_shift, int32_t *point_list, int32_t *ranges /* pre-zeroed */, int32_t *edge, hipStream_t s);
 
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
-hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
+hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *acc, int64_t n, int shift,
                                       const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s);
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
-                             hipStream_t s);
+                             int32_t *zero_acc, int zero_n /* accumulators of the first partition pass, cleared here */, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                     const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */, hipStream_t s);
 

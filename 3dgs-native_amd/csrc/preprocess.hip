@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int32_t *__restrict__ radii, float *__restrict__ xy, float *__restrict__ depths, float *__restrict__ cov3Ds,
     float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
-    uint64_t *__restrict__ depth_item, int dbg)
+    uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int dbg)
 {
+    // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
+    for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
     // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -255,6 +257,7 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     const unsigned blocks = (unsigned)gsr_div_up(sc.N, threads);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
-                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, gsr_debug_flags);
+                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, ws.acc[0],
+                       (int)gsr_radix_acc_ints(sc.N), gsr_debug_flags);
     return hipGetLastError();
 }

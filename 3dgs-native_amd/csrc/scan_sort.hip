@@ -130,10 +130,19 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 // Chunk = 256 * ITEMS items per block (each wave owns 64*ITEMS consecutive items).  ITEMS = 16 for the big
 // D-item passes (fewer, fatter blocks); ITEMS = 4 when n is small, so the launch still fills the chip.
 
-// block histogram of the digit; hist is digit-major [256][nb]
+// Per pass two kernels (round 1 had a third, a row scan over the block histograms, between them: six 5-us launches per
+// frame that each scanned under a megabyte).  The histogram kernel writes its block's counts block-major, hist[block][digit],
+// and also ADDS them into a small accumulator array (sb adds per address: one row of totals over ALL blocks measured 10 us
+// per pass of same-address serialisation at nb = 1024):
+//     acc[256 + (block / sb) * 256 + d]   total of digit d over the super-block of `sb` consecutive blocks
+// from which the scatter kernel of the same pass rebuilds, per digit, the digit's total (all nb / sb super-blocks) and the
+// number of items before its block (the super-blocks before its own, plus the blocks before it inside its own, < sb rows of
+// hist) -- about 2 sqrt(nb) coalesced 16-byte loads spread over the block instead of a launch.  acc[0..255] receives the
+// totals from block 0 of a FINAL scatter (ranges_fixup_kernel reads them).  The accumulators of a pass are zeroed by the kernel that precedes its
+// histogram kernel in the stream (preprocess / expand for the first pass, the previous pass's scatter after that).
 template <int RADIX_ITEMS, int BITS, typename ItemT>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int64_t n,
-                                                         int shift, int nb)
+__global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int32_t *__restrict__ acc,
+                                                         int64_t n, int shift, int sb)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
@@ -154,41 +163,11 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
         if (k < n) atomicAdd(&h[(int)((item[r] >> shift) & (RADIX - 1))], 1);
     }
     __syncthreads();
-    if (threadIdx.x < RADIX) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
-}
-
-// one WAVE per digit: exclusive scan of its row of nb block counts in place; totals[d] = row sum.
-// The row is walked in batches of 16 coalesced rounds whose loads are all issued before the first scan: with one
-// load -> scan -> store per iteration the kernel was a chain of nb/64 memory round trips (9.8 us per launch at C3,
-// six launches per frame); batched it pays one or two.
-__global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ totals, int nb, int radix)
-{
-    constexpr int RB = 16;
-    const int lane = threadIdx.x & 63;
-    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (d >= radix) return;
-    int32_t *row = hist + (size_t)d * nb;
-    int carry = 0;
-    for (int base = 0; base < nb; base += 64 * RB) {
-        int v[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int k = base + r * 64 + lane;
-            v[r] = k < nb ? row[k] : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int inc = wave_incl_scan(v[r]);
-            v[r] = carry + inc - v[r];
-            carry += __shfl(inc, 63, 64);
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int k = base + r * 64 + lane;
-            if (k < nb) row[k] = v[r];
-        }
+    if (threadIdx.x < RADIX) {
+        const int c = h[threadIdx.x];
+        hist[(size_t)blockIdx.x * RADIX + threadIdx.x] = c;
+        if (c) atomicAdd(&acc[256 + (blockIdx.x / sb) * 256 + threadIdx.x], c);
     }
-    if (lane == 0) totals[d] = carry;
 }
 
 // CARRY (last depth pass only): the item's tile rectangle is fetched by id and written, with its tile count, to the
@@ -212,13 +191,15 @@ struct ScatterFinal {
     int32_t *edge_first;  // [RADIX * nb] tile of the run's first item, -1 for an empty run
     int32_t *edge_last;   // [RADIX * nb] tile of the run's last item
     int32_t *edge_pos;    // [RADIX * nb] output position of the run's first item
+    int32_t *totals;      // [RADIX] items per digit, for ranges_fixup_kernel (written by block 0)
     int id_shift;
 };
 
 template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
-                                                            const int32_t *__restrict__ hist, const int32_t *__restrict__ totals,
-                                                            int64_t n, int shift, int nb, ScatterCarry carry, ScatterFinal fin)
+                                                            const int32_t *__restrict__ hist, const int32_t *__restrict__ acc,
+                                                            int64_t n, int shift, int nb, int sb, int32_t *__restrict__ zero_acc, int zero_n,
+                                                            ScatterCarry carry, ScatterFinal fin)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
@@ -227,6 +208,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
     __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
     __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
+    __shared__ int s_before[RADIX];                // items of each digit in earlier blocks
+    __shared__ int s_total[RADIX];                 // items of each digit in all blocks
     __shared__ int s_dcnt[FINAL ? RADIX : 1];      // FINAL: items of each digit in this block
     __shared__ int s_tmp[4];
 
@@ -238,7 +221,11 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     if (tid < RADIX) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_wcnt[k][tid] = 0;
+        s_before[tid] = 0;
+        s_total[tid] = 0;
     }
+    // the next pass's accumulators (see radix_hist_kernel) are cleared here: nothing reads them before that pass's histogram
+    for (int z = blockIdx.x * 256 + tid; z < zero_n; z += gridDim.x * 256) zero_acc[z] = 0;
     __syncthreads();
 
     // pass 1: rank every item among equal digits of its wave, in index order
@@ -252,6 +239,23 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const int64_t k = wave_base + r * 64 + lane;
         const ItemT v = in[k < n ? k : n - 1];
         item[r] = k < n ? v : (ItemT)~(ItemT)0;
+    }
+    // items of each digit in earlier blocks = whole super-blocks (accumulators) + the earlier blocks of the own super-block
+    // (block histograms): about 2 sqrt(nb) terms per digit, spread over the block's 256 / RADIX threads per digit, coalesced
+    // along the digit; in flight during the ranking
+    int4 before_part = make_int4(0, 0, 0, 0), total_part = make_int4(0, 0, 0, 0);
+    constexpr int TPT = RADIX / 4;  // threads per term: each adds four consecutive digits (one 16-byte load)
+    {
+        constexpr int GROUPS = 256 / TPT;
+        const int d4 = (tid % TPT) * 4, my_sb = blockIdx.x / sb, nsuper = (nb + sb - 1) / sb;
+        const int nterms = nsuper + ((int)blockIdx.x - my_sb * sb);
+#pragma unroll 4
+        for (int t = tid / TPT; t < nterms; t += GROUPS) {
+            const int32_t *row = t < nsuper ? acc + 256 + (size_t)t * 256 : hist + (size_t)(my_sb * sb + (t - nsuper)) * RADIX;
+            const int4 v = *reinterpret_cast<const int4 *>(row + d4);
+            if (t < nsuper) { total_part.x += v.x; total_part.y += v.y; total_part.z += v.z; total_part.w += v.w; }
+            if (t < my_sb || t >= nsuper) { before_part.x += v.x; before_part.y += v.y; before_part.z += v.z; before_part.w += v.w; }
+        }
     }
     if constexpr (CARRY) { // the random rectangle fetches are in flight during the ranking
         // raw 8-byte loads at a clamped index, no branch: as `valid ? rect[id] : {}` each fetch got its own exec-masked
@@ -289,6 +293,17 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         if (valid && before == 0) s_wcnt[w][d] = old + __popcll(peers);
         rank[r] = old + before;
     }
+    {
+        const int d4 = (tid % TPT) * 4;
+        if (before_part.x) atomicAdd(&s_before[d4 + 0], before_part.x);
+        if (before_part.y) atomicAdd(&s_before[d4 + 1], before_part.y);
+        if (before_part.z) atomicAdd(&s_before[d4 + 2], before_part.z);
+        if (before_part.w) atomicAdd(&s_before[d4 + 3], before_part.w);
+        if (total_part.x) atomicAdd(&s_total[d4 + 0], total_part.x);
+        if (total_part.y) atomicAdd(&s_total[d4 + 1], total_part.y);
+        if (total_part.z) atomicAdd(&s_total[d4 + 2], total_part.z);
+        if (total_part.w) atomicAdd(&s_total[d4 + 3], total_part.w);
+    }
     __syncthreads();
 
     // per digit: prefix over the 4 waves, block total, then exclusive scan over digits
@@ -306,13 +321,16 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         }
         int tot;
         const int inc = block_incl_scan_256(run, s_tmp, &tot);
-        // digit base over the whole array = sum of totals of smaller digits
-        const int td = own ? totals[d] : 0;
+        // digit base over the whole array = sum of totals of smaller digits; then the items of this digit in earlier blocks:
+        // whole super-blocks from the accumulators, the rest of the own super-block from the block histograms
+        const int td = own ? s_total[d] : 0;
+        const int before = own ? s_before[d] : 0;
         const int tinc = block_incl_scan_256(td, s_tmp, &tot);
         if (own) {
             s_dstart[d] = inc - run;
-            s_gbase[d] = tinc - td + hist[(size_t)d * nb + blockIdx.x];
+            s_gbase[d] = tinc - td + before;
             if constexpr (FINAL) {
+                if (blockIdx.x == 0) fin.totals[d] = td;
                 s_dcnt[d] = run;
                 if (run == 0) fin.edge_first[(size_t)d * nb + blockIdx.x] = -1;
             }
@@ -440,8 +458,11 @@ __global__ __launch_bounds__(1024) void ranges_fixup_kernel(const int32_t *__res
 template <typename ItemT>
 __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ doff,
                                                      const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n,
-                                                     int grid_x, int64_t D, int id_shift, int32_t *__restrict__ ranges, int ranges_n)
+                                                     int grid_x, int64_t D, int id_shift, int32_t *__restrict__ ranges, int ranges_n,
+                                                     int32_t *__restrict__ zero_acc, int zero_n)
 {
+    // the accumulators of the first partition pass (radix_hist_kernel) are cleared here, like the ranges below
+    for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
     // also clears the tile ranges (filled later by ranges_kernel; untouched tiles must read (0,0)): saves a memset launch
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < ranges_n; z += (int64_t)gridDim.x * 256) ranges[z] = 0;
     __shared__ int s_off[4][64];
@@ -509,32 +530,50 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     return hipGetLastError();
 }
 
-template <int BITS, typename ItemT>
-static void radix_pass_bits(const ItemT *in, ItemT *out, int32_t *hist, int32_t *totals, int64_t n, int shift, hipStream_t s)
+// chunk size and super-block size of a pass over n items (gsr_internal.h: gsr_radix_blocks, gsr_radix_sb)
+struct PassGeom {
+    bool small;
+    int nb, sb;
+};
+static PassGeom pass_geom(int64_t n)
 {
-    constexpr int RADIX = 1 << BITS;
-    if (n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64)) { // GSR_DEBUG bit 6: take the large-n path at any n (tests)
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{}, ScatterFinal{});
-    } else {
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, ScatterCarry{}, ScatterFinal{});
-    }
+    PassGeom g;
+    g.small = n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64); // GSR_DEBUG bit 6: take the large-n path at any n (tests)
+    g.nb = (int)gsr_div_up(n, g.small ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK);
+    g.sb = gsr_radix_sb(g.nb);
+    return g;
 }
 
-template <typename ItemT>
-static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, hipStream_t s)
+template <int BITS, typename ItemT, bool CARRY, bool FINAL>
+static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int32_t *zero_acc, int zero_n,
+                              const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s)
 {
+    const PassGeom g = pass_geom(n);
+    if (g.small) {
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
+                           n, shift, g.nb, g.sb, zero_acc, zero_n, carry, fin);
+    } else {
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
+                           shift, g.nb, g.sb, zero_acc, zero_n, carry, fin);
+    }
+    if constexpr (FINAL)
+        hipLaunchKernelGGL(ranges_fixup_kernel, dim3(1 << BITS), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, acc, g.nb, 1 << BITS,
+                           fin.ranges);
+}
+
+template <typename ItemT, bool FINAL>
+static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int32_t *zero_acc,
+                                 int zero_n, const ScatterFinal &fin, hipStream_t s)
+{
+    const ScatterCarry nc{};
     switch (bits) {
-    case 4: radix_pass_bits<4, ItemT>(in, out, hist, totals, n, shift, s); break;
-    case 5: radix_pass_bits<5, ItemT>(in, out, hist, totals, n, shift, s); break;
-    case 6: radix_pass_bits<6, ItemT>(in, out, hist, totals, n, shift, s); break;
-    case 7: radix_pass_bits<7, ItemT>(in, out, hist, totals, n, shift, s); break;
-    case 8: radix_pass_bits<8, ItemT>(in, out, hist, totals, n, shift, s); break;
+    case 4: radix_pass_launch<4, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
+    case 5: radix_pass_launch<5, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
+    case 6: radix_pass_launch<6, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
+    case 7: radix_pass_launch<7, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
+    case 8: radix_pass_launch<8, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -543,89 +582,49 @@ static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int
 // One stable pass on the `bits`-wide digit at `shift` (bits in 4..8).  Ranking costs one ballot per digit bit,
 // so passes use the narrowest digits that cover the key: 6+6 bits for the 12-bit tile ids of an 800x800 image.
 // item_bytes: 8 (uint64 items) or 4 (uint32 items: tile id and Gaussian id share one word when they fit).
-hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits,
-                                 int item_bytes, hipStream_t s)
+// `acc`: this pass's accumulators (gsr_radix_acc_ints(n) ints, zero when the pass's first kernel runs); `zero_acc`: the
+// accumulators of the NEXT pass over the same n, cleared by this pass's scatter (or NULL).
+hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
+                                 int32_t *zero_acc, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    if (item_bytes == 4) return radix_pass_any<uint32_t>((const uint32_t *)in, (uint32_t *)out, hist, totals, n, shift, bits, s);
-    return radix_pass_any<uint64_t>((const uint64_t *)in, (uint64_t *)out, hist, totals, n, shift, bits, s);
+    const int zero_n = zero_acc ? (int)gsr_radix_acc_ints(n) : 0;
+    if (item_bytes == 4)
+        return radix_pass_any<uint32_t, false>((const uint32_t *)in, (uint32_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s);
+    return radix_pass_any<uint64_t, false>((const uint64_t *)in, (uint64_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s);
 }
 
-// The LAST pass of the tile partition: histogram, row scan, then a scatter that writes point_list and the in-sight range
-// boundaries directly (ScatterFinal), and the edge fix-up.  `edge` holds 3 * (1 << bits) * nb int32 (gsr_radix_blocks(n) = nb).
-template <int BITS, typename ItemT>
-static void radix_final_bits(const ItemT *in, int32_t *hist, int32_t *totals, int64_t n, int shift, const ScatterFinal &fin, hipStream_t s)
-{
-    constexpr int RADIX = 1 << BITS;
-    if (n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64)) {
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, false, true>), dim3(nb), dim3(256), 0, s, in, (ItemT *)nullptr,
-                           hist, totals, n, shift, nb, ScatterCarry{}, fin);
-        hipLaunchKernelGGL(ranges_fixup_kernel, dim3(RADIX), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, totals, nb, RADIX, fin.ranges);
-    } else {
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((RADIX + 3) / 4), dim3(256), 0, s, hist, totals, nb, RADIX);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, false, true>), dim3(nb), dim3(256), 0, s, in, (ItemT *)nullptr, hist,
-                           totals, n, shift, nb, ScatterCarry{}, fin);
-        hipLaunchKernelGGL(ranges_fixup_kernel, dim3(RADIX), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, totals, nb, RADIX, fin.ranges);
-    }
-}
-
-template <typename ItemT>
-static hipError_t radix_final_any(const ItemT *in, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, const ScatterFinal &fin, hipStream_t s)
-{
-    switch (bits) {
-    case 4: radix_final_bits<4, ItemT>(in, hist, totals, n, shift, fin, s); break;
-    case 5: radix_final_bits<5, ItemT>(in, hist, totals, n, shift, fin, s); break;
-    case 6: radix_final_bits<6, ItemT>(in, hist, totals, n, shift, fin, s); break;
-    case 7: radix_final_bits<7, ItemT>(in, hist, totals, n, shift, fin, s); break;
-    case 8: radix_final_bits<8, ItemT>(in, hist, totals, n, shift, fin, s); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *totals, int64_t n, int shift, int bits, int item_bytes,
+// The LAST pass of the tile partition: histogram, then a scatter that writes point_list and the in-sight range boundaries
+// directly (ScatterFinal), and the edge fix-up.  `edge` holds 3 * (1 << bits) * nb int32 (gsr_radix_blocks(n) = nb).
+hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
                                        int id_shift, int32_t *point_list, int32_t *ranges, int32_t *edge, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const size_t per = ((size_t)1 << bits) * (size_t)gsr_radix_blocks(n);
-    const ScatterFinal fin{point_list, ranges, edge, edge + per, edge + 2 * per, id_shift};
-    if (item_bytes == 4) return radix_final_any<uint32_t>((const uint32_t *)in, hist, totals, n, shift, bits, fin, s);
-    return radix_final_any<uint64_t>((const uint64_t *)in, hist, totals, n, shift, bits, fin, s);
+    const ScatterFinal fin{point_list, ranges, edge, edge + per, edge + 2 * per, acc, id_shift};
+    if (item_bytes == 4) return radix_pass_any<uint32_t, true>((const uint32_t *)in, (uint32_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s);
+    return radix_pass_any<uint64_t, true>((const uint64_t *)in, (uint64_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s);
 }
 
 // The last pass of the depth sort (8-bit digit of 64-bit items) with the rectangle carry.
-hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *totals, int64_t n, int shift,
+hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *acc, int64_t n, int shift,
                                       const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const ScatterCarry carry{rect, rect_sorted, cnt_sorted};
-    if (n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64)) { // GSR_DEBUG bit 6: take the large-n path at any n (tests)
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_SMALL_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry, ScatterFinal{});
-    } else {
-        const int nb = (int)gsr_div_up(n, GSR_RADIX_CHUNK);
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t>), dim3(nb), dim3(256), 0, s, in, hist, n, shift, nb);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(64), dim3(256), 0, s, hist, totals, nb, 256);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, 8, uint64_t, true>), dim3(nb), dim3(256), 0, s, in, out, hist, totals, n, shift, nb, carry, ScatterFinal{});
-    }
+    radix_pass_launch<8, uint64_t, true, false>(in, out, hist, acc, n, shift, nullptr, 0, carry, ScatterFinal{}, s);
     return hipGetLastError();
 }
 
 hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,
-                             int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n, hipStream_t s)
+                             int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n,
+                             hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
     const dim3 grid((unsigned)gsr_div_up(n, 256));
     if (item_bytes == 4)
-        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n);
+        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
     else
-        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n);
+        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
     return hipGetLastError();
 }

@@ -99,11 +99,12 @@ def test_needle_splats_against_both_checkers(oracle, cameras, scenes, seed):
         # Not standard: then the array is ill-conditioned HERE (only dL_dmean3D ever is: the cov2d backward's 1/(det^2 + 1e-7)
         # amplifies 1e-7 differences of dL_dconic by 1e4..1e5).  The yardstick is how far two float32 evaluations of the same
         # sums land from each other: the reference-order sum vs the exact one, and the kernel vs itself on a second run.  The
-        # kernel must have as many elements inside as the worse of the two; its LARGEST error is a maximum over a heavy-tailed
+        # kernel may have as many elements outside as the two together; its LARGEST error is a maximum over a heavy-tailed
         # set (one element, amplified 1e4..1e5 times) and may be 6x the larger of the two yardsticks -- a wrong kernel is off by
         # the size of the gradient itself (the bugs this sweep has caught were), not by a factor of a few of rounding noise.
         yard = max(e_o, spread)
-        assert standard or (e_g <= 6.0 * yard + 1e-6 and ok_g >= min(ok_o, ok_s) - slack), \
+        # elements outside: at most those the float32 rounding puts outside plus those the summation order does (union bound)
+        assert standard or (e_g <= 6.0 * yard + 1e-6 and (1.0 - ok_g) <= (1.0 - ok_o) + (1.0 - ok_s) + slack), \
             f"{k}: kernel {ok_g:.5f} inside / max {e_g:.2e}, float32 reference order {ok_o:.5f} / {e_o:.2e}, run-to-run {ok_s:.5f} / {spread:.2e}"
     if seed == 0 or os.environ.get("GSR_FUZZ_VERBOSE"):
         print(f"\nneedle case {seed} ({W}x{H}): array, kernel [frac inside, max err/max|g|] vs f64-accumulated; float32 reference order likewise; kernel run-to-run")
