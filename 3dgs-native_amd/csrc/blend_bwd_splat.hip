@@ -31,7 +31,7 @@
 #ifdef GSR_TIMELINE
 constexpr int TLB_MAX_WAVES = 1 << 17;
 __device__ unsigned long long g_bwd_wave[TLB_MAX_WAVES][8];
-#define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, (unsigned long long)tl_t, 0, 0}; /* [5] = start */
 #define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
 #define TL_COUNT(k, v) tl_acc[k] += (v);
 #define TL_FLUSH if (threadIdx.x == 0) { const int tw = blockIdx.x & (TLB_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_bwd_wave[tw][q] = tl_acc[q]; }
@@ -146,9 +146,13 @@ __device__ __forceinline__ bool block_may_hit(float gx, float gy, float ca, floa
 // three terms cancel to a few units out of 1e4..1e6, and a fused form replays alphas that differ from the forward's by
 // per cent: tests/test_gpu_fuzz.py seed 63 had dL_dconic 3.5 % off for a 1.28 x 0.008 x 0.003 Gaussian.
 #pragma clang fp contract(off)
-__device__ __forceinline__ float power_ref_order(float ca, float cb, float cc, float dx, float dy)
+// With the conic pre-scaled to (-a/2, -b, -c/2) the same roundings come out of one multiply less: scaling by a power of two
+// commutes with rounding, so (-a/2 dx) dx + (-c/2 dy) dy = -0.5 (a dx dx + c dy dy) and (-b dx) dy = -(b dx dy) bit for bit
+// (blend_fwd.hip stages its records the same way).  The dy term is the same for a whole pixel row: row_term() once per row.
+__device__ __forceinline__ float row_term(float cc2, float dy) { return (cc2 * dy) * dy; }
+__device__ __forceinline__ float power_ref_order(float ca2, float cb2, float tc, float dx, float dy)
 {
-    return -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+    return ((ca2 * dx) * dx + tc) + (cb2 * dx) * dy;
 }
 #pragma clang fp contract(fast)
 
@@ -169,9 +173,10 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     constexpr int NPIX = BW * BH;            // pixels of the block this wave owns
     constexpr int PER_TILE = 256 / NPIX;     // blocks per 16x16 tile
     constexpr int NBX = 16 / BW;
-    __shared__ float4 s_pa[NPIX];   // px, py, Tfin, bgdot*Tfin
+    // px, py, and the pixel's two carries between buckets: T = T_final * product of deeper 1/(1-alpha) (the transmittance in
+    // front of the next bucket's deepest entry) and Q = T_final (bg . dpix) + sum of deeper alpha*T*(c . dpix)
+    __shared__ float4 s_pq[NPIX];
     __shared__ float4 s_pb[NPIX];   // dpix r,g,b, kept (as int bits)
-    __shared__ float2 s_carry[NPIX]; // R (product of deeper 1/(1-alpha)), Q (sum of deeper alpha*T*(c.dpix))
     __shared__ int2 s_ring[QCAP];   // compacted survivors: (Gaussian id, list index); records are re-gathered (L2 hits)
     __shared__ float s_g[64][9];    // per-entry gradients for the transposed flush (odd stride: no bank conflicts)
     __shared__ int s_id[64];
@@ -199,9 +204,8 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         float bgdot = bg0 * d0;
         bgdot += bg1 * d1;
         bgdot += bg2 * d2;
-        s_pa[lane] = make_float4((float)my_x, (float)my_y, Tfin, Tfin * bgdot);
+        s_pq[lane] = make_float4((float)my_x, (float)my_y, Tfin, Tfin * bgdot);
         s_pb[lane] = make_float4(d0, d1, d2, __int_as_float(kept));
-        s_carry[lane] = make_float2(1.0f, 0.0f);
     }
     const int hi_all = wave_max_i(kept);
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
@@ -282,30 +286,29 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         //   Sxx = sum h dx^2         Sxy = sum h dx dy  Syy = sum h dy^2      Sop = sum G dL/dalpha
         float g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, S1 = 0.f, S2 = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sop = 0.f;
         bool touched = false;
+        const float ca2 = -0.5f * a.z, cb2 = -a.w, cc2 = -0.5f * b.x; // exact
 
 #define GSR_PIXEL_STEP(Q, SCAN_MUL, SCAN_ADD, CARRY_LANE)                                                                      \
     {                                                                                                                         \
-        const float4 pa = s_pa[Q];                                                                                            \
-        const float2 carry = s_carry[Q];                                                                                      \
-        const float d_x = a.x - pa.x, d_y = a.y - pa.y;                                                                       \
-        const float power = power_ref_order(a.z, a.w, b.x, d_x, d_y);                                                         \
+        const float4 pq = s_pq[Q];                                                                                            \
+        const float d_x = a.x - pq.x;                                                                                         \
+        const float power = power_ref_order(ca2, cb2, tc, d_x, d_y);                                                          \
         const float G = fast_exp(power);                                                                                      \
         const float alpha = fminf(0.99f, b.y * G);                                                                            \
         const bool live = (idx < pkept) && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));                                      \
         const float inv = fast_rcp(1.0f - alpha); /* 1/(1-alpha): scanned as a product, and reused in dL/dalpha */            \
         const float m = live ? inv : 1.0f;                                                                                    \
         const float Pi = SCAN_MUL(m);                                                                                         \
-        const float rdenom = carry.x * Pi; /* product of 1/(1-alpha) over this entry and everything deeper */                 \
-        const float T = pa.z * rdenom;     /* transmittance in front of this entry = T_final / prod(1-alpha) */               \
+        const float T = pq.z * Pi; /* transmittance in front of this entry = T_final / prod(1-alpha) over it and all deeper */ \
         const float cd = b.z * pb.x + b.w * pb.y + colb * pb.z;                                                               \
         const float w = alpha * T;                                                                                            \
         const float qv = live ? w * cd : 0.0f;                                                                                \
         const float Qi = SCAN_ADD(qv);                                                                                        \
-        if (CARRY_LANE) s_carry[Q] = make_float2(rdenom, carry.y + Qi);                                                       \
+        if (CARRY_LANE) *reinterpret_cast<float2 *>(&s_pq[Q].z) = make_float2(T, pq.w + Qi);                                  \
         if (live) {                                                                                                           \
             touched = true;                                                                                                   \
-            const float Qe = carry.y + (Qi - qv); /* deeper entries only */                                                   \
-            const float dL_dalpha = T * cd - (Qe + pa.w) * inv;                                                               \
+            const float Qe = pq.w + (Qi - qv); /* background term + deeper entries only */                                    \
+            const float dL_dalpha = T * cd - Qe * inv;                                                                        \
             g_c0 += w * pb.x; g_c1 += w * pb.y; g_c2 += w * pb.z;                                                             \
             const float gd = G * dL_dalpha;                                                                                   \
             Sop += gd;                                                                                                        \
@@ -315,22 +318,29 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
             Sxx += hx * d_x; Sxy += hx * d_y; Syy += hy * d_y;                                                                \
         }                                                                                                                     \
     }
+        const int rows_run = GSR_ABL(dbg, 2) ? 1 : BH;
         if (!two) {
-            for (int q = 0; q < (GSR_ABL(dbg, 2) ? 1 : NPIX); ++q) {
-                const float4 pb = s_pb[q];
-                const int pkept = __float_as_int(pb.w);
-                if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
-                TL_COUNT(7, 1ull)
-                GSR_PIXEL_STEP(q, wave_scan_mul, wave_scan_add, lane == 63)
+            for (int r = 0; r < rows_run; ++r) {
+                const float d_y = a.y - (fy0 + (float)r), tc = row_term(cc2, d_y);
+                for (int q = r * BW; q < (GSR_ABL(dbg, 2) ? 1 : (r + 1) * BW); ++q) {
+                    const float4 pb = s_pb[q];
+                    const int pkept = __float_as_int(pb.w);
+                    if (pkept <= idx_min) continue; // wave-uniform: this pixel's replay ends before every entry of the bucket
+                    TL_COUNT(7, 1ull)
+                    GSR_PIXEL_STEP(q, wave_scan_mul, wave_scan_add, lane == 63)
+                }
             }
         } else {
             const int sub = lane >> 5;
-            for (int q2 = 0; q2 < (GSR_ABL(dbg, 2) ? 2 : NPIX); q2 += 2) {
-                const int q = q2 + sub;
-                const float4 pb = s_pb[q];
-                const int pkept = __float_as_int(pb.w);
-                TL_COUNT(7, 1ull)
-                GSR_PIXEL_STEP(q, half_scan_mul, half_scan_add, (lane & 31) == 31)
+            for (int r = 0; r < rows_run; ++r) {
+                const float d_y = a.y - (fy0 + (float)r), tc = row_term(cc2, d_y);
+                for (int q2 = r * BW; q2 < (GSR_ABL(dbg, 2) ? 2 : (r + 1) * BW); q2 += 2) {
+                    const int q = q2 + sub;
+                    const float4 pb = s_pb[q];
+                    const int pkept = __float_as_int(pb.w);
+                    TL_COUNT(7, 1ull)
+                    GSR_PIXEL_STEP(q, half_scan_mul, half_scan_add, (lane & 31) == 31)
+                }
             }
             // an entry's sums are split over its two lanes: add the halves (lanes 32-63 then hold copies and stay out of the flush)
             g_c0 += __shfl_xor(g_c0, 32, 64); g_c1 += __shfl_xor(g_c1, 32, 64); g_c2 += __shfl_xor(g_c2, 32, 64);
@@ -343,8 +353,8 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
 #undef GSR_PIXEL_STEP
         TL(3) // pixel loop
         // dL/dmean2D = dL/dG * dG/ddel * 0.5*(W,H), dG/ddelx = -G (a dx + b dy); dL/dconic = -0.5 h (dx^2, dx dy, dy^2)
-        const float g_mx = -(a.z * S1 + a.w * S2) * ddelx_dx;
-        const float g_my = -(b.x * S2 + a.w * S1) * ddely_dy;
+        const float g_mx = (2.0f * ca2 * S1 + cb2 * S2) * ddelx_dx; // = -(a S1 + b S2) 0.5 W
+        const float g_my = (2.0f * cc2 * S2 + cb2 * S1) * ddely_dy; // = -(c S2 + b S1) 0.5 H
         const float g_ca = -0.5f * Sxx, g_cb = -0.5f * Sxy, g_cc = -0.5f * Syy, g_op = Sop;
 
         // transpose through LDS: 16 lanes per entry -> one 64-byte accumulator record each

@@ -95,7 +95,7 @@ def test_needle_splats_against_both_checkers(oracle, cameras, scenes, seed):
         rows.append((k, ok_g, e_g, ok_o, e_o, spread))
         need = min(0.999, 1.0 - 4.0 / max(1, parity.to_np(g1[k]).size))
         standard = ok_g >= need and e_g <= parity.GRAD_REST
-        slack = max(2e-3, 4.0 / max(1, parity.to_np(g1[k]).size))       # small arrays: one Gaussian's components
+        slack = max(5e-3, 4.0 / max(1, parity.to_np(g1[k]).size))       # small arrays: one Gaussian's components; 5e-3: two builds of the same kernel (other FMA choices) moved this fraction by 3e-3
         # Not standard: then the array is ill-conditioned HERE (only dL_dmean3D ever is: the cov2d backward's 1/(det^2 + 1e-7)
         # amplifies 1e-7 differences of dL_dconic by 1e4..1e5).  The yardstick is how far two float32 evaluations of the same
         # sums land from each other: the reference-order sum vs the exact one, and the kernel vs itself on a second run.  The

@@ -35,3 +35,26 @@ for k, nme in enumerate(names):
     print(f"  {nme:30s} mean {col.mean():9.0f}  p50 {np.median(col):9.0f}  p95 {np.percentile(col, 95):9.0f} cycles/wave  {100.0 * col.sum() / tot.sum():5.1f} %")
 steps = arr[:, 7].astype(np.float64)
 print(f"  cycles per (bucket, pixel) step (wave mean): {(arr[:, 3].astype(np.float64)[steps > 0] / steps[steps > 0]).mean():.0f}")
+
+# occupancy over the kernel's life from the waves' start ([5]) and end (start + phases) stamps.  Every XCD has its own counter
+# (offsets of 1e11 cycles): the waves are grouped by counter domain, one curve per XCD, 1024 wave slots each at 8 waves per SIMD.
+start_all = arr[:, 5].astype(np.float64)
+life_all = tot
+print("per XCD: span (cycles), waves, mean resident waves (of 1024 slots), then resident waves at 5 % steps of the span")
+order = np.argsort(start_all)
+cuts = np.flatnonzero(np.diff(start_all[order]) > 2e6) + 1 # a new counter domain wherever consecutive starts are > 2e6 cycles apart
+for x, grp in enumerate(np.split(order, cuts)):
+    st, lf = start_all[grp], life_all[grp]
+    ok = st > 0
+    st, lf = st[ok], lf[ok]
+    if st.size == 0:
+        continue
+    en = st + lf
+    t0, t1 = st.min(), en.max()
+    ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    conc = np.cumsum(ev[:, 1])
+    pts = [int(conc[np.searchsorted(ev[:, 0], t0 + f * (t1 - t0), side="right") - 1]) for f in np.linspace(0.025, 0.975, 20)]
+    print(f"  XCD {x}: span {t1 - t0:8.0f}, {ok.sum()} waves, mean {lf.sum() / (t1 - t0):6.0f} | " + " ".join(f"{v:4d}" for v in pts))
+life = tot[start_all > 0]
+print(f"wave life: p10 {np.percentile(life, 10):.0f} p50 {np.percentile(life, 50):.0f} p90 {np.percentile(life, 90):.0f} p99 {np.percentile(life, 99):.0f} max {life.max():.0f}")
