@@ -65,8 +65,10 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
 static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_N ? (n + GSR_RADIX_SMALL_CHUNK - 1) / GSR_RADIX_SMALL_CHUNK : (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
 // A pass's blocks are grouped into super-blocks of about sqrt(nb) blocks; its accumulators are 256 digit totals followed by
 // 256 per super-block (scan_sort.hip, radix_hist_kernel).
+#define GSR_RADIX_PREFIX_NB 2048 // passes over more blocks than this scan their super-block rows first (radix_superscan_kernel)
 static inline int gsr_radix_sb(int nb)
 {
+    if (nb > GSR_RADIX_PREFIX_NB) return 32;
     int sb = 16;
     while ((int64_t)sb * sb < nb) ++sb;
     return sb;
@@ -106,15 +108,16 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
-// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks -- same results by
+// GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks, bit 7 the scanned
+// super-block rows of many-block radix passes (radix_superscan_kernel) -- same results by
 // other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
 // one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->
 // libgsr_hip_ablate.so, -DGSR_ABLATE, used by tools/stage_bench.sh) and are compiled out of libgsr_hip.so.
 #ifdef GSR_ABLATE
-#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64)
+#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128)
 #define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
 #else
-#define GSR_DEBUG_ALLOWED (32 | 64)
+#define GSR_DEBUG_ALLOWED (32 | 64 | 128)
 #define GSR_ABL(flags, bit) false
 #endif
 extern int gsr_debug_flags;

@@ -170,6 +170,44 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     }
 }
 
+// Passes over many blocks (nb > GSR_RADIX_PREFIX_NB; C5's tile partition has 7 866) put one small launch between the two
+// kernels after all: with only the two-level sums a scatter block read ~1.5 sqrt(nb) rows (68 KB per block, 0.5 GB per pass at
+// C5: tile partition 395 -> 435 us).  One workgroup turns the super-block rows into exclusive prefixes in place and writes the
+// digit totals to acc[0..255]; super-blocks are then a fixed 32 blocks, so a scatter block reads 2 + (< 32) rows.
+__global__ __launch_bounds__(1024) void radix_superscan_kernel(int32_t *__restrict__ acc, int nsuper)
+{
+    __shared__ int4 s_part[16][64];
+    const int q = threadIdx.x & 63, g = threadIdx.x >> 6; // 64 threads x 4 digits per row; 16 groups, a contiguous share of rows each
+    const int per = (nsuper + 15) / 16, t0 = g * per, t1 = min(nsuper, t0 + per);
+    int4 *rows = reinterpret_cast<int4 *>(acc + 256) + q;
+    int4 sum = make_int4(0, 0, 0, 0);
+#pragma unroll 8
+    for (int t = t0; t < t1; ++t) {
+        const int4 v = rows[(size_t)t * 64];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    s_part[g][q] = sum;
+    __syncthreads();
+    int4 run = make_int4(0, 0, 0, 0), all = run;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int4 v = s_part[k][q];
+        if (k < g) { run.x += v.x; run.y += v.y; run.z += v.z; run.w += v.w; }
+        all.x += v.x; all.y += v.y; all.z += v.z; all.w += v.w;
+    }
+    if (g == 0) reinterpret_cast<int4 *>(acc)[q] = all;
+    for (int tb = t0; tb < t1; tb += 8) { // eight rows at a time: loads together, then the stores
+        int4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tb + k < t1 ? rows[(size_t)(tb + k) * 64] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (tb + k < t1) rows[(size_t)(tb + k) * 64] = run;
+            run.x += v[k].x; run.y += v[k].y; run.z += v[k].z; run.w += v[k].w;
+        }
+    }
+}
+
 // CARRY (last depth pass only): the item's tile rectangle is fetched by id and written, with its tile count, to the
 // item's final position -- so the depth-order scan and the expansion stream rect_sorted / cnt_sorted instead of each
 // gathering through the sorted ids (two random 64-byte-sector reads per Gaussian become one).
@@ -198,18 +236,20 @@ struct ScatterFinal {
 template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ acc,
-                                                            int64_t n, int shift, int nb, int sb, int32_t *__restrict__ zero_acc, int zero_n,
-                                                            ScatterCarry carry, ScatterFinal fin)
+                                                            int64_t n, int shift, int nb, int sb, bool prefixed, int32_t *__restrict__ zero_acc,
+                                                            int zero_n, ScatterCarry carry, ScatterFinal fin)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
     __shared__ ItemT s_items[CHUNK];    // items reordered by digit
     __shared__ unsigned long long s_rect[CARRY ? CHUNK : 1]; // CARRY: the items' rectangles (raw bits), reordered with them
     __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
-    __shared__ int s_dstart[RADIX];                // first LDS slot of each digit
-    __shared__ int s_gbase[RADIX];                 // global position of the block's first item of each digit
     __shared__ int s_before[RADIX];                // items of each digit in earlier blocks
     __shared__ int s_total[RADIX];                 // items of each digit in all blocks
+    // thread d reads [d] of the two arrays above into registers before it writes [d] of these two: they share the space
+    // (2 KB that decide between 3 and 4 workgroups per CU for 64-bit items with 8-bit digits)
+    int *const s_dstart = s_total;                 // first LDS slot of each digit
+    int *const s_gbase = s_before;                 // global position of the block's first item of each digit
     __shared__ int s_dcnt[FINAL ? RADIX : 1];      // FINAL: items of each digit in this block
     __shared__ int s_tmp[4];
 
@@ -228,6 +268,52 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     for (int z = blockIdx.x * 256 + tid; z < zero_n; z += gridDim.x * 256) zero_acc[z] = 0;
     __syncthreads();
 
+    // items of each digit in earlier blocks = whole super-blocks (accumulators) + the earlier blocks of the own super-block
+    // (block histograms): about 2 sqrt(nb) terms per digit, spread over the block's 256 / RADIX threads per digit, coalesced
+    // along the digit.  Done BEFORE the items are loaded: in flight under the ranking (or beside the item loads) the partial sums
+    // and the unrolled loads' targets cost 20-30 registers (4 -> 3 waves per SIMD for 64-bit items: C5's tile partition 395 ->
+    // 435 us); the one exposed round trip costs less
+    int4 before_part = make_int4(0, 0, 0, 0), total_part = make_int4(0, 0, 0, 0);
+    constexpr int TPT = RADIX / 4;  // threads per term: each adds four consecutive digits (one 16-byte load)
+    {
+        constexpr int GROUPS = 256 / TPT;
+        const int d4 = (tid % TPT) * 4, g = tid / TPT, my_sb = blockIdx.x / sb, nsuper = (nb + sb - 1) / sb;
+        // (two plain strided loops, so that each unrolled body issues its loads together)
+        const int32_t *rows = hist + (size_t)my_sb * sb * RADIX + d4; // the earlier blocks of the own super-block
+        const int within = (int)blockIdx.x - my_sb * sb;
+#pragma unroll 4
+        for (int t = g; t < within; t += GROUPS) {
+            const int4 v = *reinterpret_cast<const int4 *>(rows + (size_t)t * RADIX);
+            before_part.x += v.x; before_part.y += v.y; before_part.z += v.z; before_part.w += v.w;
+        }
+        if (prefixed) { // many blocks: radix_superscan_kernel left the totals and every super-block's exclusive prefix
+            if (g == 0) {
+                total_part = *reinterpret_cast<const int4 *>(acc + d4);
+                const int4 v = *reinterpret_cast<const int4 *>(acc + 256 + (size_t)my_sb * 256 + d4);
+                before_part.x += v.x; before_part.y += v.y; before_part.z += v.z; before_part.w += v.w;
+            }
+        } else {
+            const int32_t *sup = acc + 256 + d4;
+#pragma unroll 4
+            for (int t = g; t < nsuper; t += GROUPS) {
+                const int4 v = *reinterpret_cast<const int4 *>(sup + (size_t)t * 256);
+                total_part.x += v.x; total_part.y += v.y; total_part.z += v.z; total_part.w += v.w;
+                if (t < my_sb) { before_part.x += v.x; before_part.y += v.y; before_part.z += v.z; before_part.w += v.w; }
+            }
+        }
+    }
+    {
+        const int d4 = (tid % TPT) * 4;
+        if (before_part.x) atomicAdd(&s_before[d4 + 0], before_part.x);
+        if (before_part.y) atomicAdd(&s_before[d4 + 1], before_part.y);
+        if (before_part.z) atomicAdd(&s_before[d4 + 2], before_part.z);
+        if (before_part.w) atomicAdd(&s_before[d4 + 3], before_part.w);
+        if (total_part.x) atomicAdd(&s_total[d4 + 0], total_part.x);
+        if (total_part.y) atomicAdd(&s_total[d4 + 1], total_part.y);
+        if (total_part.z) atomicAdd(&s_total[d4 + 2], total_part.z);
+        if (total_part.w) atomicAdd(&s_total[d4 + 3], total_part.w);
+    }
+
     // pass 1: rank every item among equal digits of its wave, in index order
     ItemT item[RADIX_ITEMS];
     unsigned long long rc[CARRY ? RADIX_ITEMS : 1]; // raw TileRect bits
@@ -239,23 +325,6 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const int64_t k = wave_base + r * 64 + lane;
         const ItemT v = in[k < n ? k : n - 1];
         item[r] = k < n ? v : (ItemT)~(ItemT)0;
-    }
-    // items of each digit in earlier blocks = whole super-blocks (accumulators) + the earlier blocks of the own super-block
-    // (block histograms): about 2 sqrt(nb) terms per digit, spread over the block's 256 / RADIX threads per digit, coalesced
-    // along the digit; in flight during the ranking
-    int4 before_part = make_int4(0, 0, 0, 0), total_part = make_int4(0, 0, 0, 0);
-    constexpr int TPT = RADIX / 4;  // threads per term: each adds four consecutive digits (one 16-byte load)
-    {
-        constexpr int GROUPS = 256 / TPT;
-        const int d4 = (tid % TPT) * 4, my_sb = blockIdx.x / sb, nsuper = (nb + sb - 1) / sb;
-        const int nterms = nsuper + ((int)blockIdx.x - my_sb * sb);
-#pragma unroll 4
-        for (int t = tid / TPT; t < nterms; t += GROUPS) {
-            const int32_t *row = t < nsuper ? acc + 256 + (size_t)t * 256 : hist + (size_t)(my_sb * sb + (t - nsuper)) * RADIX;
-            const int4 v = *reinterpret_cast<const int4 *>(row + d4);
-            if (t < nsuper) { total_part.x += v.x; total_part.y += v.y; total_part.z += v.z; total_part.w += v.w; }
-            if (t < my_sb || t >= nsuper) { before_part.x += v.x; before_part.y += v.y; before_part.z += v.z; before_part.w += v.w; }
-        }
     }
     if constexpr (CARRY) { // the random rectangle fetches are in flight during the ranking
         // raw 8-byte loads at a clamped index, no branch: as `valid ? rect[id] : {}` each fetch got its own exec-masked
@@ -292,17 +361,6 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const int old = valid ? s_wcnt[w][d] : 0;
         if (valid && before == 0) s_wcnt[w][d] = old + __popcll(peers);
         rank[r] = old + before;
-    }
-    {
-        const int d4 = (tid % TPT) * 4;
-        if (before_part.x) atomicAdd(&s_before[d4 + 0], before_part.x);
-        if (before_part.y) atomicAdd(&s_before[d4 + 1], before_part.y);
-        if (before_part.z) atomicAdd(&s_before[d4 + 2], before_part.z);
-        if (before_part.w) atomicAdd(&s_before[d4 + 3], before_part.w);
-        if (total_part.x) atomicAdd(&s_total[d4 + 0], total_part.x);
-        if (total_part.y) atomicAdd(&s_total[d4 + 1], total_part.y);
-        if (total_part.z) atomicAdd(&s_total[d4 + 2], total_part.z);
-        if (total_part.w) atomicAdd(&s_total[d4 + 3], total_part.w);
     }
     __syncthreads();
 
@@ -532,7 +590,7 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
 
 // chunk size and super-block size of a pass over n items (gsr_internal.h: gsr_radix_blocks, gsr_radix_sb)
 struct PassGeom {
-    bool small;
+    bool small, prefixed;
     int nb, sb;
 };
 static PassGeom pass_geom(int64_t n)
@@ -541,6 +599,7 @@ static PassGeom pass_geom(int64_t n)
     g.small = n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64); // GSR_DEBUG bit 6: take the large-n path at any n (tests)
     g.nb = (int)gsr_div_up(n, g.small ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK);
     g.sb = gsr_radix_sb(g.nb);
+    g.prefixed = g.nb > GSR_RADIX_PREFIX_NB || (gsr_debug_flags & 128); // GSR_DEBUG bit 7: at any block count (tests)
     return g;
 }
 
@@ -551,12 +610,14 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
     const PassGeom g = pass_geom(n);
     if (g.small) {
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb);
+        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
-                           n, shift, g.nb, g.sb, zero_acc, zero_n, carry, fin);
+                           n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin);
     } else {
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb);
+        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
-                           shift, g.nb, g.sb, zero_acc, zero_n, carry, fin);
+                           shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin);
     }
     if constexpr (FINAL)
         hipLaunchKernelGGL(ranges_fixup_kernel, dim3(1 << BITS), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, acc, g.nb, 1 << BITS,
