@@ -276,7 +276,7 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.rect_sorted = c.take<TileRect>((size_t)N);
     w.cnt_sorted = c.take<int32_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);
-    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4);
+    w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, 256) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
     w.acc[0] = c.take<int32_t>(gsr_radix_acc_ints(N));
     w.acc[1] = c.take<int32_t>(gsr_radix_acc_ints(N));
@@ -339,7 +339,8 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     Readback *rb = lease.r;
     if (!rb) return GSR_E_HIP;
     // the scan's last wave stores D = point_offsets[N-1] straight into the pinned host word
-    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, s));
+    // (preprocess left one partial sum per 256 Gaussians in scan_tmp: one launch)
+    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s));
     mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
     // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id order, four 8-bit
@@ -355,7 +356,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
         // the last pass also carries each Gaussian's tile rectangle and tile count to its sorted position
         HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.acc[1], N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
         mark(st, 3, s);
-        HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, s));
+        HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
         mark(st, 4, s);
     }
     HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting

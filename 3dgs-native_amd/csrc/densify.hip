@@ -217,7 +217,7 @@ int gsr_split_removal_mask(int64_t n_total, int64_t offset, const int32_t *split
     return done();
 }
 
-size_t gsr_mask_scan_workspace_bytes(int64_t N) { return N <= 0 ? 256 : gsr_align((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) * sizeof(int32_t)); }
+size_t gsr_mask_scan_workspace_bytes(int64_t N) { return N <= 0 ? 256 : gsr_align(((size_t)gsr_div_up(N, GSR_SCAN_WAVE_ITEMS) + 4) * sizeof(int32_t)); } // + 4: read as int4
 
 int gsr_mask_scan(int64_t N, const int32_t *mask, int32_t *prefix, int32_t *count_host, void *scratch, size_t scratch_bytes, void *stream)
 {
@@ -226,9 +226,10 @@ int gsr_mask_scan(int64_t N, const int32_t *mask, int32_t *prefix, int32_t *coun
     *count_host = 0;
     if (N == 0) return GSR_OK;
     if (!mask || !prefix || !scratch) return GSR_E_NULL;
+    if (!gsr_aligned16(scratch)) return GSR_E_ALIGN;
     if (scratch_bytes < gsr_mask_scan_workspace_bytes(N)) return GSR_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (gsr_launch_scan(mask, nullptr, prefix, (int32_t *)scratch, N, 2, nullptr, s) != hipSuccess) return GSR_E_HIP;
+    if (gsr_launch_scan(mask, nullptr, prefix, (int32_t *)scratch, N, 2, nullptr, false, s) != hipSuccess) return GSR_E_HIP;
     // the reference's count is the LAST ENTRY of the exclusive scan (train.py:433, 497, 581, 641)
     if (hipMemcpyAsync(count_host, prefix + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return GSR_E_HIP;
     return hipStreamSynchronize(s) == hipSuccess ? GSR_OK : GSR_E_HIP;

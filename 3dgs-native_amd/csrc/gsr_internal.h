@@ -42,7 +42,7 @@ struct GeomWs {
     TileRect *rect_sorted; // [N] tile rectangles in depth order (written by the last depth-sort pass)
     int32_t *cnt_sorted;  // [N] tile counts in depth order (same pass)
     int32_t *doff;        // [N] exclusive tile-pair offsets in depth order
-    int32_t *scan_tmp;    // block sums for the scans
+    int32_t *scan_tmp;    // [N / 256 + 4] partial sums for the scans (preprocess writes one per 256 Gaussians)
     int32_t *hist;        // [nb(N)][256] radix block histograms
     int32_t *acc[2];      // [gsr_radix_acc_ints(N)] each: digit + super-block totals of a pass; consecutive passes alternate
     size_t bytes;
@@ -56,7 +56,8 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 // mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
-                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */, hipStream_t s);
+                           int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */,
+                           bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s);
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int32_t *__restrict__ radii, float *__restrict__ xy, float *__restrict__ depths, float *__restrict__ cov3Ds,
     float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
-    uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int dbg)
+    uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ block_tile_sums, int dbg)
 {
+    __shared__ int s_tiles[4];
     // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
     // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
@@ -166,6 +167,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
     }
 
+    // the block's tile count, for the id-order scan (scan_sort.hip: its reduce pass is this)
+    {
+        int t = in_range ? o_tiles : 0; // tail lanes redo the last Gaussian
+        // DPP adds (no LDS round trips, unlike six ds_bpermute steps): lane 63 ends up with the wave's sum
+        t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xF, 0xF, false); // row_shr:1
+        t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xF, 0xF, false); // row_shr:2
+        t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xF, 0xF, false); // row_shr:4
+        t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xF, 0xF, false); // row_shr:8
+        t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+        t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+        if (lane == 63) s_tiles[wv] = t;
+    }
     sh_rows_commit(sh_regs, lds_wave, lane);
     // in_range: tail lanes redo the last Gaussian; their rows do not exist (found by tests/test_gpu_fuzz.py: N = 1, one big
     // splat centred outside the frustum -> 63 rows read past the end of the SH array)
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         sh_rows_commit_masked(sh_regs, lds_wave, lane, late_mask);
     }
     __syncthreads(); // SH rows have landed in LDS
+    if (threadIdx.x == 0) block_tile_sums[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian
                 const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
@@ -258,6 +272,6 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
                        g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, ws.acc[0],
-                       (int)gsr_radix_acc_ints(sc.N), gsr_debug_flags);
+                       (int)gsr_radix_acc_ints(sc.N), ws.scan_tmp, gsr_debug_flags);
     return hipGetLastError();
 }

@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
     if (lane == 0) wave_sums[wid] = s;
 }
 
-template <int MODE>
+// SUMS_PER_UNIT: `wave_sums` holds that many partial sums per 1024-item unit (1 from scan_reduce_kernel; 4 when the kernel that
+// produced `in` wrote one sum per 256 items itself -- preprocess does, which saves the reduce launch of the id-order scan).
+template <int MODE, int SUMS_PER_UNIT>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
                                                          int32_t *__restrict__ out, int64_t n, int32_t *total_out)
 {
@@ -102,8 +104,18 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
         v[r] = (k < n) ? in[k] : 0;
     }
     // this wave's offset = sum of the sums of all earlier waves: a few KB read per wave beats a third kernel launch
+    // (16-byte loads, four in flight: as a scalar loop this was up to 16 dependent round trips for the last waves; the array is
+    // padded by 4 ints, elements at or past the limit are masked)
     int carry = 0;
-    for (int64_t j = lane; j < wid; j += 64) carry += wave_sums[j];
+    {
+        const int limit = (int)wid * SUMS_PER_UNIT;
+        const int4 *s4 = reinterpret_cast<const int4 *>(wave_sums);
+#pragma unroll 4
+        for (int j = lane * 4; j < limit; j += 256) {
+            const int4 q = s4[j >> 2];
+            carry += q.x + (j + 1 < limit ? q.y : 0) + (j + 2 < limit ? q.z : 0) + (j + 3 < limit ? q.w : 0);
+        }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) carry += __shfl_xor(carry, d, 64);
     int32_t total = 0;
@@ -570,18 +582,20 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
 } // namespace
 
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
-                           int32_t *total_out, hipStream_t s)
+                           int32_t *total_out, bool sums_per_256_ready, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
     const int nb = (nw + 3) / 4;
     (void)items;
-    if (mode == 0) {
+    if (mode == 0 && sums_per_256_ready) { // block_tmp already holds one sum per 256 items (preprocess.hip)
+        hipLaunchKernelGGL((scan_final_kernel<0, 4>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+    } else if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+        hipLaunchKernelGGL((scan_final_kernel<0, 1>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else if (mode == 2) {
         hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL(scan_final_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+        hipLaunchKernelGGL((scan_final_kernel<2, 1>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
     } else {
         return hipErrorInvalidValue;
     }
