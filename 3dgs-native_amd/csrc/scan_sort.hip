@@ -545,6 +545,9 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     int off = (int)D;
     TileRect rc = {0, 0, 0, 0};
     uint32_t id = 0;
+    // (requested with the wave's other loads: read where it is used, after the barrier, it was a second serial round trip)
+    int next_off = (k0 + 64 < n) ? doff[k0 + 64] : (int)D;
+    asm volatile("" : "+v"(next_off));
     if (k < n) {
         const uint64_t it = sorted[k];
         id = (uint32_t)it;
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     if (k0 >= n) return;
     const int begin = s_off[w][0];
     // never write past the caller's D, even if it under-reports the count gsr_forward_count returned
-    const int end = min((int)D, (k0 + 64 < n) ? doff[k0 + 64] : (int)D);
+    const int end = min((int)D, next_off);
     for (int j = begin + lane; j < end; j += 64) {
         int lo = 0; // last k with off[k] <= j (zero-count Gaussians share their successor's offset)
 #pragma unroll
