@@ -156,7 +156,14 @@ __device__ __forceinline__ float power_ref_order(float ca2, float cb2, float tc,
 }
 #pragma clang fp contract(fast)
 
-constexpr int QCAP = 128; // ring of compacted entries (power of two, >= 2*64 - 1)
+// Candidate chunks (of 64) requested per fill iteration on the masks path.  More chunks per memory round trip shorten the fill
+// (a quarter of a wave's life) but the ring grows with them, and its LDS is occupancy: at C3 1 / 2 / 4 chunks ran the kernel in
+// 170.0 / 177.4 / 175.1 us.
+#ifndef GSR_FILL_K
+#define GSR_FILL_K 1
+#endif
+constexpr int FILL_K = GSR_FILL_K;
+constexpr int QCAP = 128 * FILL_K;        // ring of compacted entries (power of two, >= 63 + 64 * FILL_K)
 
 // USE_MASKS: the per-block hit masks the forward wrote (GsrBinning.block_masks) replace the compaction's own test.  They are
 // per 8x4 block; an 8x8 block ORs the bits of its two halves, a 4x4 block keeps its own (finer) test.
@@ -221,19 +228,36 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     for (;;) {
         // ---- fill: pull candidates (deepest first) until a full bucket is queued or the list is exhausted ----
         while (qn < 64 && cursor > start) {
+            if (USE_MASKS) {
+                // The forward already tested every staged entry against the tile's eight 8x4 blocks (blend_fwd.hip): one byte
+                // per entry, read coalesced, instead of two 16-byte gathers and the convex test per candidate.  FILL_K chunks of
+                // 64 candidates are requested together, one memory round trip per iteration.
+                int ids[FILL_K], mvs[FILL_K];
+#pragma unroll
+                for (int j = 0; j < FILL_K; ++j) {
+                    const int idx = cursor - 1 - (j * 64 + lane);
+                    ids[j] = 0; mvs[j] = 0;
+                    if (idx >= start) {
+                        ids[j] = point_list[idx];
+                        mvs[j] = (int)block_masks[idx];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FILL_K; ++j) {
+                    const int idx = cursor - 1 - (j * 64 + lane);
+                    const bool hit = idx >= start && ((mvs[j] >> mask_shift) & mask_bits) != 0;
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) s_ring[(head + qn + __popcll(m & lt_mask)) & (QCAP - 1)] = make_int2(ids[j], idx);
+                    qn += __popcll(m);
+                }
+                cursor = max(start, cursor - 64 * FILL_K);
+                continue;
+            }
             const int lo = max(start, cursor - 64);
             const int idx = cursor - 1 - lane;
             bool hit = false;
             int id = 0;
-            if (USE_MASKS) {
-                // the forward already tested every staged entry against the tile's eight 8x4 blocks (blend_fwd.hip): one byte
-                // per entry, read coalesced, instead of two 16-byte gathers and the convex test per candidate
-                if (idx >= lo) {
-                    id = point_list[idx];
-                    const int mv = (int)block_masks[idx];
-                    hit = ((mv >> mask_shift) & mask_bits) != 0;
-                }
-            } else if (idx >= lo) {
+            if (idx >= lo) {
                 id = point_list[idx];
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + id);
                 float4 a = rp[0], b = rp[1];
