@@ -230,23 +230,23 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         const bool contributes = !(t < (1.0f / 255.0f));                                                                      \
         const float a_eff = contributes ? t : 0.0f;                                                                           \
         const float test_T = T * (1.0f - a_eff); /* forward.py:486 */                                                          \
+        float w = a_eff * T, T_next = test_T; /* a_eff = 0 where the entry does not contribute: w = 0 and T_next = T exactly */ \
+        bool counts = contributes;                                                                                            \
         if (__builtin_amdgcn_ballot_w64(test_T < 0.0001f) != 0ull) {                                                          \
-            /* some pixel saturates at this entry (forward.py:487-489): the entry is not applied there and the pixel ends */  \
+            /* some pixel saturates at this entry (forward.py:487-489): the entry is not applied there and the pixel ends.    \
+               Only these four values change; the updates below are one code path (as two, hipcc reconciled the register     \
+               sets of the two paths with six v_mov per entry on the COMMON one) */                                          \
             const bool sat = contributes && (test_T < 0.0001f);                                                               \
-            const bool apply = contributes && !sat;                                                                           \
-            const float w = apply ? a_eff * T : 0.0f;                                                                         \
-            cr = __builtin_fmaf(R.b.z, w, cr); cg = __builtin_fmaf(R.b.w, w, cg);                                             \
-            cb = __builtin_fmaf(R.c.x, w, cb); cd = __builtin_fmaf(R.c.y, w, cd);                                             \
-            if (apply) { last_off = OFF; T = test_T; }                                                                        \
+            w = sat ? 0.0f : w;                                                                                               \
+            T_next = sat ? T : T_next;                                                                                        \
+            counts = contributes && !sat;                                                                                     \
             if (sat) pixf_x = PARKED_X; /* the pixel is finished (`done` is re-derived from this after the walk) */           \
-            if (__all(pixf_x == PARKED_X)) break; /* the wave's 64 pixels are saturated: nothing later can contribute */      \
-        } else {                                                                                                              \
-            const float w = a_eff * T;                                                                                        \
-            cr = __builtin_fmaf(R.b.z, w, cr); cg = __builtin_fmaf(R.b.w, w, cg);                                             \
-            cb = __builtin_fmaf(R.c.x, w, cb); cd = __builtin_fmaf(R.c.y, w, cd);                                             \
-            if (contributes) last_off = OFF;                                                                                  \
-            T = test_T;                                                                                                       \
+            if (__all(pixf_x == PARKED_X)) break; /* all 64 pixels are saturated (none of them applies this entry either) */  \
         }                                                                                                                     \
+        cr = __builtin_fmaf(R.b.z, w, cr); cg = __builtin_fmaf(R.b.w, w, cg);                                                 \
+        cb = __builtin_fmaf(R.c.x, w, cb); cd = __builtin_fmaf(R.c.y, w, cd);                                                 \
+        if (counts) last_off = OFF;                                                                                           \
+        T = T_next;                                                                                                           \
     }
         int off0 = lp[0], off1 = lp[1];
         StagedRec r0 = fetch(off0);
