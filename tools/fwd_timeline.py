@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (GSR_TIMELINE build of blend_fwd.hip only): per-phase shader-cycle totals of the forward blend over all waves.
-usage: GSR_LIB=ab/lib_fwdtl.so python tools/fwd_timeline.py [C3]"""
+usage: make -C 3dgs-native_amd/csrc timeline; GSR_LIB=$PWD/3dgs-native_amd/libgsr_hip_timeline.so python tools/fwd_timeline.py [C3]"""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
