@@ -63,16 +63,7 @@ __device__ __forceinline__ void sh_rows_store(float4 *__restrict__ g4, const flo
     for (int k = 0; k < 12; ++k) {
         const int i = k * 64 + lane;
         const int r = i / 12, c = i - r * 12;
-        // Non-temporal: the 192 bytes per Gaussian of SH gradient are streamed out and not read again by this library, and as
-        // ordinary stores they push the SH coefficients -- which the next forward's preprocess reads first -- out of the
-        // last-level cache: preprocess 85 -> 76 us at C3 when frames follow each other, this kernel +2 us (NT stores drain
-        // slower; with every output of the geometry backward non-temporal it lost 6 us for the same gain).
-        if (r < rows_valid) {
-            typedef float nt_f4 __attribute__((ext_vector_type(4)));
-            const float4 v = lds_wave[r * SH_ROW_F4 + c];
-            nt_f4 w = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(w, reinterpret_cast<nt_f4 *>(&g4[i]));
-        }
+        if (r < rows_valid) g4[i] = lds_wave[r * SH_ROW_F4 + c];
     }
 }
 
