@@ -30,11 +30,25 @@
 // GSR_TIMELINE (diagnostic build only, never the product): per-phase shader cycles of every wave (tools/bwd_timeline.py)
 #ifdef GSR_TIMELINE
 constexpr int TLB_MAX_WAVES = 1 << 17;
-__device__ unsigned long long g_bwd_wave[TLB_MAX_WAVES][8];
-#define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, (unsigned long long)tl_t, 0, 0}; /* [5] = start */
+__device__ unsigned long long g_bwd_wave[TLB_MAX_WAVES][12];
+// [5] = start (shader clock), [8] = HW_ID | XCC_ID << 32, [9] / [10] = s_memrealtime (100 MHz, chip-wide) at start / end
+#define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, (unsigned long long)tl_t, 0, 0};
 #define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
 #define TL_COUNT(k, v) tl_acc[k] += (v);
-#define TL_FLUSH if (threadIdx.x == 0) { const int tw = blockIdx.x & (TLB_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_bwd_wave[tw][q] = tl_acc[q]; }
+#define TL_FLUSH if (threadIdx.x == 0) { const int tw = blockIdx.x & (TLB_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_bwd_wave[tw][q] = tl_acc[q]; \
+        g_bwd_wave[tw][8] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
+        g_bwd_wave[tw][9] = tl_r0; g_bwd_wave[tw][10] = __builtin_amdgcn_s_memrealtime(); }
+#elif defined(GSR_CENSUS)
+// GSR_CENSUS (diagnostic build, `make census`): the product kernel, same registers and LDS, plus three scalar stamps per wave --
+// where it ran (HW_ID, XCC_ID) and its s_memrealtime start / end -- so residency per CU is measured on the real code object
+// (the GSR_TIMELINE build needs 94 VGPRs: its waves are capped at 5 per SIMD, the product's 62 are not).  tools/residency.py
+__device__ unsigned long long g_bwd_census[1 << 17][4];
+#define TL_DECL const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#define TL(k)
+#define TL_COUNT(k, v)
+#define TL_FLUSH if (threadIdx.x == 0) { unsigned long long *cw = g_bwd_census[blockIdx.x & ((1 << 17) - 1)]; \
+        cw[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
+        cw[1] = tl_r0; cw[2] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define TL_DECL
 #define TL(k)
@@ -427,11 +441,23 @@ hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, h
     return hipGetLastError();
 }
 
+#ifdef GSR_CENSUS
+extern "C" int gsr_debug_bwd_census(unsigned long long *out /* [waves][4] */, int waves, int clear)
+{
+    if (waves > (1 << 17)) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bwd_census)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 4 * (size_t)waves) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_census), sizeof(unsigned long long) * 4 * (size_t)waves) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef GSR_TIMELINE
-extern "C" int gsr_debug_bwd_phases(unsigned long long *out /* [waves][8] */, int waves)
+extern "C" int gsr_debug_bwd_phases(unsigned long long *out /* [waves][12] */, int waves)
 {
     if (waves > TLB_MAX_WAVES) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_wave), sizeof(unsigned long long) * 8 * (size_t)waves) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_wave), sizeof(unsigned long long) * 12 * (size_t)waves) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -34,6 +34,16 @@ __device__ unsigned long long g_fwd_wave[TL_MAX_WAVES][8]; // one row per wave, 
 #define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
 #define TL_COUNT(k, v) tl_acc[k] += (v);
 #define TL_FLUSH if (lane == 0) { const int tw = (blockIdx.x * 4 + wv) & (TL_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_fwd_wave[tw][q] = tl_acc[q]; }
+#elif defined(GSR_CENSUS)
+// GSR_CENSUS (diagnostic build, `make census`): the product kernel plus three scalar stamps per wave (HW_ID | XCC_ID,
+// s_memrealtime start / end) for tools/residency.py
+__device__ unsigned long long g_fwd_census[1 << 17][4];
+#define TL_DECL const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#define TL(k)
+#define TL_COUNT(k, v)
+#define TL_FLUSH if (lane == 0) { unsigned long long *cw = g_fwd_census[(blockIdx.x * 4 + wv) & ((1 << 17) - 1)]; \
+        cw[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
+        cw[1] = tl_r0; cw[2] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define TL_DECL
 #define TL(k)
@@ -284,6 +294,18 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
 
 } // namespace
 
+#ifdef GSR_CENSUS
+extern "C" int gsr_debug_fwd_census(unsigned long long *out /* [waves][4] */, int waves, int clear)
+{
+    if (waves > (1 << 17)) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fwd_census)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 4 * (size_t)waves) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_census), sizeof(unsigned long long) * 4 * (size_t)waves) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef GSR_TIMELINE
 extern "C" int gsr_debug_fwd_phases(unsigned long long *out /* [waves][8] */, int waves)
 {

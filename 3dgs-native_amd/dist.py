@@ -29,6 +29,9 @@ MAX_VIEWS_PER_CALL = 16      # GSR_MAX_VIEWS of include/gsr.h
 def init_from_env(backend=None, device=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # dmabuf IPC is what this pool's host driver supports; RCCL reads the variable when it first opens a peer's memory, so a
+    # rank that did not inherit it (torch.distributed.run does not add it) still gets it here, before the process group exists
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():

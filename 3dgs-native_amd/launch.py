@@ -15,6 +15,9 @@ import subprocess
 import sys
 
 
+TERM_GRACE_S = 5.0   # between terminate() and kill() for the ranks that outlive a failed one
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -48,21 +51,27 @@ def launch_ranks(script, argv, gpus, timeout=None):
         pending = list(procs)
         import time
         t0 = time.monotonic()
+        stop_at = None                       # when the survivors were told to stop (a rank failed, or the time limit passed)
         while pending:
             for p in list(pending):
                 rc = p.poll()
                 if rc is None:
                     continue
                 pending.remove(p)
-                if rc != 0:
-                    worst = rc if worst == 0 else worst
+                if rc != 0 and stop_at is None:
+                    worst = rc
+                    stop_at = time.monotonic()
                     for q in pending:        # one rank failed: the collective can never complete, stop the rest
                         q.terminate()
-            if timeout is not None and time.monotonic() - t0 > timeout:
-                worst = worst or 124
+            if stop_at is None and timeout is not None and time.monotonic() - t0 > timeout:
+                worst = 124
+                stop_at = time.monotonic()
                 for q in pending:
                     q.terminate()
-                timeout = None
+            if stop_at is not None and time.monotonic() - stop_at > TERM_GRACE_S:
+                for q in pending:            # blocked in a driver or collective call and deaf to SIGTERM
+                    q.kill()
+                stop_at = float("inf")
             time.sleep(0.05)
     finally:
         for p in procs:

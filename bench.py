@@ -32,6 +32,9 @@ import os
 import sys
 import time
 
+# Before torch (and with it the HIP runtime) is imported: under `python -m torch.distributed.run ... bench.py` nobody else sets it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

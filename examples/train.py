@@ -21,6 +21,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# before torch / the HIP runtime load: dmabuf IPC is what this pool's driver supports, and a rank started by torch.distributed.run
+# (not by launch.py) would otherwise never get it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def _self_launch():

@@ -25,7 +25,7 @@ for _ in range(3):
                  binning_buffer={"point_list": buf["point_list"]}, img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]})
 torch.cuda.synchronize()
 waves = ((W + 15) // 16) * ((H + 15) // 16) * 8
-arr = np.zeros((waves, 8), np.uint64)
+arr = np.zeros((waves, 12), np.uint64)
 assert L.gsr_debug_bwd_phases(arr.ctypes.data_as(C.c_void_p), waves) == 0
 names = ["prologue", "fill (compaction)", "record gather", "pixel loop", "flush (transpose + atomics)"]
 tot = arr[:, :5].sum(axis=1).astype(np.float64)
@@ -36,25 +36,33 @@ for k, nme in enumerate(names):
 steps = arr[:, 7].astype(np.float64)
 print(f"  cycles per (bucket, pixel) step (wave mean): {(arr[:, 3].astype(np.float64)[steps > 0] / steps[steps > 0]).mean():.0f}")
 
-# occupancy over the kernel's life from the waves' start ([5]) and end (start + phases) stamps.  Every XCD has its own counter
-# (offsets of 1e11 cycles): the waves are grouped by counter domain, one curve per XCD, 1024 wave slots each at 8 waves per SIMD.
-start_all = arr[:, 5].astype(np.float64)
-life_all = tot
-print("per XCD: span (cycles), waves, mean resident waves (of 1024 slots), then resident waves at 5 % steps of the span")
-order = np.argsort(start_all)
-cuts = np.flatnonzero(np.diff(start_all[order]) > 2e6) + 1 # a new counter domain wherever consecutive starts are > 2e6 cycles apart
-for x, grp in enumerate(np.split(order, cuts)):
-    st, lf = start_all[grp], life_all[grp]
-    ok = st > 0
-    st, lf = st[ok], lf[ok]
-    if st.size == 0:
-        continue
-    en = st + lf
-    t0, t1 = st.min(), en.max()
-    ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)])
-    ev = ev[np.argsort(ev[:, 0], kind="stable")]
-    conc = np.cumsum(ev[:, 1])
-    pts = [int(conc[np.searchsorted(ev[:, 0], t0 + f * (t1 - t0), side="right") - 1]) for f in np.linspace(0.025, 0.975, 20)]
-    print(f"  XCD {x}: span {t1 - t0:8.0f}, {ok.sum()} waves, mean {lf.sum() / (t1 - t0):6.0f} | " + " ".join(f"{v:4d}" for v in pts))
-life = tot[start_all > 0]
-print(f"wave life: p10 {np.percentile(life, 10):.0f} p50 {np.percentile(life, 50):.0f} p90 {np.percentile(life, 90):.0f} p99 {np.percentile(life, 99):.0f} max {life.max():.0f}")
+# Residency per physical CU, from each wave's HW_ID / XCC_ID ([8]) and its s_memrealtime start / end ([9], [10]: 100 MHz, one
+# counter for the whole chip).  HW_ID (gfx9): wave_id [3:0], simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13].
+ran = arr[:, 9] > 0
+hw = (arr[ran, 8] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+xcc = ((arr[ran, 8] >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
+cu_key = (xcc << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)
+simd_key = (cu_key << 2) | ((hw >> 4) & 3)
+r0, r1 = arr[ran, 9].astype(np.int64), arr[ran, 10].astype(np.int64)
+t_first, t_last = r0.min(), r1.max()
+span = float(t_last - t_first)
+print(f"kernel span {span / 100:.1f} us (s_memrealtime); {np.unique(cu_key).size} CUs, {np.unique(simd_key).size} SIMDs seen; "
+      f"mean resident waves per SIMD over the span {(r1 - r0).sum() / span / np.unique(simd_key).size:.2f}")
+def peak_and_curve(keys):
+    peaks, curves = [], []
+    grid = t_first + (np.linspace(0.025, 0.975, 20) * span).astype(np.int64)
+    for k in np.unique(keys):
+        m = keys == k
+        ev = np.concatenate([np.stack([r0[m], np.ones(m.sum(), np.int64)], 1), np.stack([r1[m], -np.ones(m.sum(), np.int64)], 1)])
+        ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+        conc = np.cumsum(ev[:, 1])
+        peaks.append(conc.max())
+        curves.append([conc[max(0, np.searchsorted(ev[:, 0], g, side="right") - 1)] for g in grid])
+    return np.array(peaks), np.array(curves, np.float64)
+pk, cv = peak_and_curve(cu_key)
+print(f"peak resident waves per CU: min {pk.min()} median {int(np.median(pk))} max {pk.max()}  (32 = 8 per SIMD)")
+print("mean resident waves per CU at 5 % steps of the span: " + " ".join(f"{v:.1f}" for v in cv.mean(axis=0)))
+pk, cv = peak_and_curve(simd_key)
+print(f"peak resident waves per SIMD: min {pk.min()} median {int(np.median(pk))} max {pk.max()}")
+life = tot[ran]
+print(f"wave life (shader cycles): p10 {np.percentile(life, 10):.0f} p50 {np.percentile(life, 50):.0f} p90 {np.percentile(life, 90):.0f} p99 {np.percentile(life, 99):.0f} max {life.max():.0f}")
