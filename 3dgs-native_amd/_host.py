@@ -26,7 +26,12 @@ def to_dev(x, dtype, dev, shape=None):
         t = torch.as_tensor(np.ascontiguousarray(np.asarray(x)), device="cpu").to(dtype).to(dev)
     if shape is not None:
         t = t.reshape(shape)
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        # include/gsr.h asks for 16-byte aligned arrays (GSR_E_ALIGN); an offset view such as means[1:] is contiguous but
+        # not aligned, and the reference (which copies every input, wp_utils.py:34-44) accepts it: copy it too
+        t = t.clone()
+    return t
 
 
 def host_f32(x, n):

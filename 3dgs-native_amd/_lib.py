@@ -26,7 +26,7 @@ class GsrCamera(C.Structure):
 
 class GsrGeom(C.Structure):
     _fields_ = [("radii", vp), ("tiles_touched", vp), ("point_offsets", vp), ("xy", vp), ("depths", vp), ("cov3D", vp),
-                ("rgb", vp), ("conic_opacity", vp), ("clamped_state", vp), ("blend_records", vp)]
+                ("rgb", vp), ("conic_opacity", vp), ("clamped_state", vp), ("blend_records", vp), ("sh_dir_grad", vp)]
 
 
 class GsrBinning(C.Structure):
@@ -111,7 +111,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gsr_abi_version() != 3:
+        if h.gsr_abi_version() != 4:
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib

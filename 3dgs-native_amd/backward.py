@@ -24,13 +24,15 @@ _ZERO = {}
 
 
 def _zeros_cov3d(n, dev):
-    """The reference returns an all-zero dL_dcov3D (backward.py:1119 is never filled).  Instead of clearing 24*N bytes every
-    call this is a stride-0 expansion of ONE zero scalar per device: reads (`.cpu().numpy()`, copies) see (N, 6) zeros, and an
-    in-place write raises instead of silently corrupting what later calls return."""
-    z = _ZERO.get(dev.index)
+    """The reference returns an all-zero dL_dcov3D (backward.py:1119 is allocated, never filled).  Here it is a real, dense
+    (N, 6) zero tensor (`.view(-1)`, `.numpy()`, strides as the reference's array) that is cleared ONCE per (N, device) and
+    then SHARED by every later call with that N: it is meant to be read.  A caller that writes into it changes what later
+    calls return; `dL_dcov3D.clone()` gives a private copy."""
+    z = _ZERO.get((n, dev.index))
     if z is None:
-        z = _ZERO[dev.index] = torch.zeros((), dtype=torch.float32, device=dev)
-    return z.expand(n, 6)
+        _ZERO.clear()                      # one size at a time: a trainer's N changes only at densification
+        z = _ZERO[(n, dev.index)] = torch.zeros((n, 6), dtype=torch.float32, device=dev)
+    return z
 
 
 def _get(buf, key):
@@ -69,7 +71,28 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
         rgb = geom_buffer.get("rgb") if rgb is None else rgb
         clamped = geom_buffer.get("clamped_state") if clamped is None else clamped
     rec_tag = getattr(means2D, "_gsr_records", None)     # set by render_gaussians on its points_xy_image tensor
-    masks = getattr(point_list, "_gsr_block_masks", None)   # ... and on its point_list tensor
+    # The forward's per-entry block masks ride on its point_list tensor.  They are conservative only for THAT forward's records
+    # and written only up to each tile's saturation batch, so they are honoured only when every buffer they were derived from
+    # or are read against is the forward's own tensor (identity, not equality): a caller who mixes in perturbed means2D /
+    # conic_opacity or another run's ranges / n_contrib gets the self-contained block test instead.
+    masks = None
+    mask_tag = getattr(point_list, "_gsr_block_masks", None)
+    if mask_tag is not None:
+        m_t, owners = mask_tag
+        given = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": means2D, "conic_opacity": conic_opacity}
+        if all(owners[k]() is given[k] for k in given):
+            masks = m_t
+    # likewise the forward's d(colour)/d(direction) sums (GsrGeom.sh_dir_grad) ride on its clamped_state tensor: used when shs
+    # and means3D are the very tensors that forward read, with the same camera position and degree -- geom_backward_kernel then
+    # reads 36 bytes per Gaussian instead of the 192 bytes of coefficients
+    sh_dir = None
+    dir_tag = getattr(clamped, "_gsr_sh_dir", None)
+    if dir_tag is not None:
+        d_t, sh_ref, means_ref, campos_f, deg_f = dir_tag
+        if (sh_ref() is shs and means_ref() is means3D and deg_f == int(degree) and d_t.device == dev
+                and campos_f == tuple(float(v) for v in _host.host_f32(campos, 3))):
+            sh_dir = d_t
+    backward.last_call_used_forward_sh_dir = sh_dir is not None     # for tests and debugging
     radii = _host.to_dev(radii, i32, dev, (-1,))
     m2d = _host.to_dev(means2D, f32, dev, (-1, 2))
     con = _host.to_dev(conic_opacity, f32, dev, (-1, 4))
@@ -86,10 +109,11 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     scene = _lib.GsrScene(N, _host.ptr(means), _host.ptr(sc), _host.ptr(rot), _host.ptr(op), _host.ptr(sh), int(degree),
                           float(scale_modifier), 1)
     geom = _lib.GsrGeom(_host.ptr(radii), None, None, _host.ptr(m2d), None, _host.ptr(c3), _host.ptr(col), _host.ptr(con),
-                        _host.ptr(cl), _host.records_ptr(rec_tag, N, dev))
+                        _host.ptr(cl), _host.records_ptr(rec_tag, N, dev), _host.ptr(sh_dir))
     if masks is not None and not (isinstance(masks, torch.Tensor) and masks.dtype == torch.uint8 and masks.device == dev
                                   and masks.numel() == D and masks.is_contiguous()):
         masks = None
+    backward.last_call_used_forward_masks = masks is not None      # for tests and debugging
     binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks))
     img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
 

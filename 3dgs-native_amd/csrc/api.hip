@@ -113,7 +113,7 @@ bool geom_aligned(const GsrGeom *g)
 {
     return gsr_aligned16(g->radii) && gsr_aligned16(g->tiles_touched) && gsr_aligned16(g->point_offsets) && gsr_aligned16(g->xy) &&
            gsr_aligned16(g->depths) && gsr_aligned16(g->cov3D) && gsr_aligned16(g->rgb) && gsr_aligned16(g->conic_opacity) &&
-           gsr_aligned16(g->clamped_state) && gsr_aligned16(g->blend_records);
+           gsr_aligned16(g->clamped_state) && gsr_aligned16(g->blend_records) && gsr_aligned16(g->sh_dir_grad);
 }
 bool grads_aligned(const GsrGrads *g)
 {

@@ -54,13 +54,18 @@ __device__ __forceinline__ float dot3(const float a[3], const float b[3])
     return r;
 }
 
+// DIRGRAD: the forward left, per visible Gaussian, the nine sums d(colour before clamping)/d(direction) that the SH backward
+// forms from the 48 coefficients (GsrGeom.sh_dir_grad, written by preprocess_kernel with these very expressions).  The kernel
+// then does not read the SH array at all: 36 instead of 192 bytes per Gaussian in, 48 fewer staging registers; the LDS image
+// only transposes the OUTPUT rows.  Without it (a caller that kept no forward state) the coefficients are read as before.
+template <bool DIRGRAD>
 __global__ __launch_bounds__(256) void geom_backward_kernel(
     int64_t N, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
     const float *__restrict__ shs, int degree, CamK cam, float h_x, float h_y, const int32_t *__restrict__ radii,
     const float *__restrict__ cov3Ds, const float *__restrict__ clamped_state, const GradRec *__restrict__ acc,
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dscale, float *__restrict__ dL_drot, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dshs, float *__restrict__ dL_dcolor, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic,
-    float *__restrict__ dL_drgb)
+    float *__restrict__ dL_drgb, const float *__restrict__ sh_dir_grad)
 {
     // SH rows (input coefficients, then in place the output gradients) live in LDS; moved cooperatively
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
@@ -74,7 +79,26 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     const int my_radius = in_range ? radii[idx] : 0;
     const unsigned long long row_mask = (degree > 0) ? __ballot(my_radius > 0) : 0ull;
     ShRegs sh_regs;
-    sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, row_mask);
+    float4 dg4[3]; // DIRGRAD: the wave's 64 x 9 floats as 144 coalesced float4 (lane, lane + 64, lane + 128)
+    if constexpr (DIRGRAD) {
+        const float *g = sh_dir_grad + 9 * wave_row0;
+        const int nfl = rows_valid * 9;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = k * 64 + lane;
+            dg4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_mask != 0ull && j < 144) {
+                if (4 * j + 3 < nfl) dg4[k] = reinterpret_cast<const float4 *>(g)[j];
+                else {
+                    if (4 * j < nfl) dg4[k].x = g[4 * j];
+                    if (4 * j + 1 < nfl) dg4[k].y = g[4 * j + 1];
+                    if (4 * j + 2 < nfl) dg4[k].z = g[4 * j + 2];
+                }
+            }
+        }
+    } else {
+        sh_rows_fetch(reinterpret_cast<const float4 *>(shs) + wave_row0 * 12, sh_regs, lane, row_mask);
+    }
     float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
 
     // phase 1 (while the SH rows are in flight): blend-gradient unpacking, cov2d and projection backward
@@ -193,8 +217,22 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     } // in_range (phase 1)
 
     // phase 2: the SH rows are parked in LDS (block barrier: must sit outside the divergent code)
-    sh_rows_commit(sh_regs, lds_wave, lane);
-    __syncthreads();
+    float dg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (DIRGRAD) {
+        // through the (still unused) LDS image: 144 float4 in, every lane takes its own nine floats (stride 9: conflict-free)
+        float4 *st = lds_wave;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k * 64 + lane < 144) st[k * 64 + lane] = dg4[k];
+        wave_lds_fence();
+        const float *mine = reinterpret_cast<const float *>(lds_wave) + 9 * lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dg[k] = mine[k];
+        wave_lds_fence(); // all lanes have read before any lane writes its output row over the staging area
+    } else {
+        sh_rows_commit(sh_regs, lds_wave, lane);
+        __syncthreads();
+    }
     if (in_range) {
     if (vis) {
         // ---------------- SH backward (backward.py:69-255) ----------------
@@ -208,10 +246,12 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                 for (int c = 0; c < 3; ++c) dRGB[c] = g_col[c] * (1.0f + (-1.0f * clamped_state[3 * idx + c]));
 #pragma unroll
                 for (int c = 0; c < 3; ++c) o_rgb[c] = dRGB[c];
+                // d(colour)/d(direction): nine sums over the coefficients (backward.py:120-244), either handed over by the forward
+                // (DIRGRAD) or formed here from the row in LDS -- the same function, the same float operations either way
+                float dx_[3] = {dg[0], dg[1], dg[2]}, dy_[3] = {dg[3], dg[4], dg[5]}, dz_[3] = {dg[6], dg[7], dg[8]};
+                if constexpr (!DIRGRAD) sh_direction_sums(row, degree, x, y, z, dx_, dy_, dz_);
+                // the gradient rows replace the coefficients in place (all reads above are done)
                 const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
-                float dx_[3] = {0.f, 0.f, 0.f}, dy_[3] = {0.f, 0.f, 0.f}, dz_[3] = {0.f, 0.f, 0.f};
-                // in-place: every read of coefficient k (SHV) happens before its slot is overwritten (OUT)
-#define SHV(k, c) row[(k) * 3 + (c)]
 #define OUT(k, coef)                                                                                                           \
     {                                                                                                                         \
         const float cf = (coef);                                                                                              \
@@ -220,42 +260,18 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                 OUT(0, SH_C0);
                 sh_written = 1;
                 if (degree > 0) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        dx_[c] = -SH_C1 * SHV(3, c);
-                        dy_[c] = -SH_C1 * SHV(1, c);
-                        dz_[c] = SH_C1 * SHV(2, c);
-                    }
                     OUT(1, -SH_C1 * y); OUT(2, SH_C1 * z); OUT(3, -SH_C1 * x);
                     sh_written = 4;
                     if (degree > 1) {
                         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                         const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
                                     C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            dx_[c] += C2_0 * y * SHV(4, c) + C2_2 * 2.0f * -x * SHV(6, c) + C2_3 * z * SHV(7, c) + C2_4 * 2.0f * x * SHV(8, c);
-                            dy_[c] += C2_0 * x * SHV(4, c) + C2_1 * z * SHV(5, c) + C2_2 * 2.0f * -y * SHV(6, c) + C2_4 * 2.0f * -y * SHV(8, c);
-                            dz_[c] += C2_1 * y * SHV(5, c) + C2_2 * 2.0f * 2.0f * z * SHV(6, c) + C2_3 * x * SHV(7, c);
-                        }
                         OUT(4, C2_0 * xy); OUT(5, C2_1 * yz); OUT(6, C2_2 * (2.0f * zz - xx - yy)); OUT(7, C2_3 * xz); OUT(8, C2_4 * (xx - yy));
                         sh_written = 9;
                         if (degree > 2) {
                             const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
                                         C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
                                         C3_6 = -0.5900435899266435f;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                dx_[c] += (C3_0 * SHV(9, c) * 3.0f * 2.0f * xy + C3_1 * SHV(10, c) * yz + C3_2 * SHV(11, c) * -2.0f * xy +
-                                           C3_3 * SHV(12, c) * -3.0f * 2.0f * xz + C3_4 * SHV(13, c) * (-3.0f * xx + 4.0f * zz - yy) +
-                                           C3_5 * SHV(14, c) * 2.0f * xz + C3_6 * SHV(15, c) * 3.0f * (xx - yy));
-                                dy_[c] += (C3_0 * SHV(9, c) * 3.0f * (xx - yy) + C3_1 * SHV(10, c) * xz +
-                                           C3_2 * SHV(11, c) * (-3.0f * yy + 4.0f * zz - xx) + C3_3 * SHV(12, c) * -3.0f * 2.0f * yz +
-                                           C3_4 * SHV(13, c) * -2.0f * xy + C3_5 * SHV(14, c) * -2.0f * yz + C3_6 * SHV(15, c) * -3.0f * 2.0f * xy);
-                                dz_[c] += (C3_1 * SHV(10, c) * xy + C3_2 * SHV(11, c) * 4.0f * 2.0f * yz +
-                                           C3_3 * SHV(12, c) * 3.0f * (2.0f * zz - xx - yy) + C3_4 * SHV(13, c) * 4.0f * 2.0f * xz +
-                                           C3_5 * SHV(14, c) * (xx - yy));
-                            }
                             OUT(9, C3_0 * y * (3.0f * xx - yy)); OUT(10, C3_1 * xy * z); OUT(11, C3_2 * y * (4.0f * zz - xx - yy));
                             OUT(12, C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)); OUT(13, C3_4 * x * (4.0f * zz - xx - yy));
                             OUT(14, C3_5 * z * (xx - yy)); OUT(15, C3_6 * x * (xx - 3.0f * yy));
@@ -263,7 +279,6 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                         }
                     }
                 }
-#undef SHV
 #undef OUT
                 const float dL_ddir[3] = {dot3(dx_, dRGB), dot3(dy_, dRGB), dot3(dz_, dRGB)};
                 // dnormvdv (backward.py:43-64)
@@ -435,9 +450,14 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
     if (sc.N <= 0) return hipSuccess;
     // focal lengths come from the host, formed in float64 and rounded once (reference backward.py:1044-1045, quirk Q8)
     const float h_x = cam.focal_x, h_y = cam.focal_y;
-    hipLaunchKernelGGL(geom_backward_kernel, dim3((unsigned)gsr_div_up(sc.N, 256)), dim3(256), 0, s, sc.N, sc.means, sc.scales,
-                       sc.rotations, sc.sh, sc.sh_degree, cam, h_x, h_y, g.radii, g.cov3D, g.clamped_state, acc, gr.dL_dmean3D,
-                       gr.dL_dscale, gr.dL_drot, gr.dL_dopacity, gr.dL_dshs, gr.dL_dcolor, gr.dL_dmean2D, gr.dL_dconic, gr.dL_drgb);
+#define GEOM_BWD(DG)                                                                                                          \
+    hipLaunchKernelGGL(geom_backward_kernel<DG>, dim3((unsigned)gsr_div_up(sc.N, 256)), dim3(256), 0, s, sc.N, sc.means, sc.scales, \
+                       sc.rotations, sc.sh, sc.sh_degree, cam, h_x, h_y, g.radii, g.cov3D, g.clamped_state, acc, gr.dL_dmean3D,  \
+                       gr.dL_dscale, gr.dL_drot, gr.dL_dopacity, gr.dL_dshs, gr.dL_dcolor, gr.dL_dmean2D, gr.dL_dconic, gr.dL_drgb, \
+                       g.sh_dir_grad)
+    if (g.sh_dir_grad) GEOM_BWD(true);
+    else GEOM_BWD(false);
+#undef GEOM_BWD
     return hipGetLastError();
 }
 

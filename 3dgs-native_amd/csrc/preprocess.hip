@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int32_t *__restrict__ radii, float *__restrict__ xy, float *__restrict__ depths, float *__restrict__ cov3Ds,
     float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
-    uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ block_tile_sums, int dbg)
+    uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ block_tile_sums,
+    float *__restrict__ sh_dir_grad, int dbg)
 {
     __shared__ int s_tiles[4];
     // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int o_radius = 0, o_tiles = 0;
     float o_xy[2] = {0.0f, 0.0f}, o_depth = 0.0f, o_cov[6] = {0, 0, 0, 0, 0, 0}, o_rgb[3] = {0, 0, 0};
     float o_con[4] = {0, 0, 0, 0}, o_cl[3] = {0, 0, 0};
+    float o_dg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // d(colour)/d(direction) for the backward (GsrGeom.sh_dir_grad), when asked for
     TileRect o_rect = {0, 0, 0, 0};
     bool visible = false, need_sh = false;
 
@@ -208,6 +210,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                 const float *sh = reinterpret_cast<const float *>(lds_wave + lane * SH_ROW_F4);
                 const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
                 const float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+                if (sh_dir_grad) {
+                    // the nine sums the SH backward would form from these same 48 coefficients (sh_stage.h): 36 bytes out here
+                    // save geom_backward_kernel 192 bytes in.  (x, y, z) are the backward's too: it divides the same
+                    // differences by the same length, and skips the Gaussian where that length is below 1e-8.
+                    float gx[3] = {0.f, 0.f, 0.f}, gy[3] = {0.f, 0.f, 0.f}, gz[3] = {0.f, 0.f, 0.f};
+                    sh_direction_sums(sh, degree, x, y, z, gx, gy, gz);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { o_dg[c] = gx[c]; o_dg[3 + c] = gy[c]; o_dg[6 + c] = gz[c]; }
+                }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
 #define SHC(k) sh[(k) * 3 + c]
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         const float v_rec[16] = {o_xy[0], o_xy[1], o_con[0], o_con[1], o_con[2], o_con[3], o_rgb[0], o_rgb[1], o_rgb[2], inv_depth, 0.0f, 0.0f,
                                  0.0f, 0.0f, 0.0f, 0.0f};
         wave_store_rows<16>(reinterpret_cast<float *>(rec + wave_row0), stage + 1024, lane, rows_valid, v_rec);
+        if (sh_dir_grad) wave_store_rows<9>(sh_dir_grad + 9 * wave_row0, stage + 2048, lane, rows_valid, o_dg);
     }
     if (!in_range) return;
     if (GSR_ABL(dbg, 8)) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
@@ -279,6 +291,6 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
                        g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, ws.acc[0],
-                       (int)gsr_radix_acc_ints(sc.N), ws.scan_tmp, gsr_debug_flags);
+                       (int)gsr_radix_acc_ints(sc.N), ws.scan_tmp, g.sh_dir_grad, gsr_debug_flags);
     return hipGetLastError();
 }

@@ -131,3 +131,52 @@ __device__ __forceinline__ void wave_store_vec3_in_pad(float *__restrict__ g, fl
                 if (4 * lane + c < nfl) g[4 * lane + c] = o[c];
     }
 }
+
+// ---- d(colour before clamping)/d(view direction): the nine sums of the reference's SH backward (backward.py:120-244) ------
+// dx[c] = sum_k d basis_k/dx (x, y, z) * sh[k][c], likewise dy, dz, in the reference's statement order.  Used by
+// geom_backward_kernel (from the coefficients) AND by preprocess_kernel, which hands the nine floats to the backward
+// (GsrGeom.sh_dir_grad) so that the backward need not read 192 bytes of coefficients per Gaussian again: one function, so the
+// two paths are the same float operations (both files are compiled with -ffp-contract=off).
+// `sh`: the Gaussian's 16 x 3 coefficients (row-major [k][c]); dx, dy, dz are overwritten when degree > 0, else left alone.
+__device__ __forceinline__ void sh_direction_sums(const float *sh, int degree, float x, float y, float z, float dx_[3], float dy_[3], float dz_[3])
+{
+#define SHV(k, c) sh[(k) * 3 + (c)]
+    const float SH_C1 = 0.4886025119029199f;
+    if (degree > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dx_[c] = -SH_C1 * SHV(3, c);
+            dy_[c] = -SH_C1 * SHV(1, c);
+            dz_[c] = SH_C1 * SHV(2, c);
+        }
+        if (degree > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                        C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dx_[c] += C2_0 * y * SHV(4, c) + C2_2 * 2.0f * -x * SHV(6, c) + C2_3 * z * SHV(7, c) + C2_4 * 2.0f * x * SHV(8, c);
+                dy_[c] += C2_0 * x * SHV(4, c) + C2_1 * z * SHV(5, c) + C2_2 * 2.0f * -y * SHV(6, c) + C2_4 * 2.0f * -y * SHV(8, c);
+                dz_[c] += C2_1 * y * SHV(5, c) + C2_2 * 2.0f * 2.0f * z * SHV(6, c) + C2_3 * x * SHV(7, c);
+            }
+            if (degree > 2) {
+                const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                            C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                            C3_6 = -0.5900435899266435f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dx_[c] += (C3_0 * SHV(9, c) * 3.0f * 2.0f * xy + C3_1 * SHV(10, c) * yz + C3_2 * SHV(11, c) * -2.0f * xy +
+                               C3_3 * SHV(12, c) * -3.0f * 2.0f * xz + C3_4 * SHV(13, c) * (-3.0f * xx + 4.0f * zz - yy) +
+                               C3_5 * SHV(14, c) * 2.0f * xz + C3_6 * SHV(15, c) * 3.0f * (xx - yy));
+                    dy_[c] += (C3_0 * SHV(9, c) * 3.0f * (xx - yy) + C3_1 * SHV(10, c) * xz +
+                               C3_2 * SHV(11, c) * (-3.0f * yy + 4.0f * zz - xx) + C3_3 * SHV(12, c) * -3.0f * 2.0f * yz +
+                               C3_4 * SHV(13, c) * -2.0f * xy + C3_5 * SHV(14, c) * -2.0f * yz + C3_6 * SHV(15, c) * -3.0f * 2.0f * xy);
+                    dz_[c] += (C3_1 * SHV(10, c) * xy + C3_2 * SHV(11, c) * 4.0f * 2.0f * yz +
+                               C3_3 * SHV(12, c) * 3.0f * (2.0f * zz - xx - yy) + C3_4 * SHV(13, c) * 4.0f * 2.0f * xz +
+                               C3_5 * SHV(14, c) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SHV
+}

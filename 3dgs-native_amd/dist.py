@@ -126,17 +126,50 @@ class FactoredExchange:
     half of the backward) overlaps `geom_backward_kernel`; the all-reduce of the 11-float arena (known after it) overlaps the
     rebuild kernel, which needs only the gathered payloads.  Single process: no collectives, same results."""
 
-    def __init__(self):
+    def __init__(self, timing=False):
         self._gathered = None
         self._work = None
+        # timing=True: five events per step on the compute stream (payload ready | before the gather wait | after it | rebuild
+        # launched, before the reduce wait | after it); `timings_ms()` turns them into the stalls the exchange really costs
+        self.timing = bool(timing)
+        self._events = []
+        self._cur = None
+
+    def _mark(self):
+        if self.timing and self._cur is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._cur.append(e)
 
     def start_gather(self, payload):
+        self._cur = [] if (self.timing and payload.is_cuda) else None
+        self._mark()
         if not dist.is_initialized() or dist.get_world_size() == 1:
             self._gathered, self._work = payload.unsqueeze(0), None
             return
         world = dist.get_world_size()
         self._gathered = torch.empty((world, payload.numel()), dtype=payload.dtype, device=payload.device)
         self._work = dist.all_gather_into_tensor(self._gathered.view(-1), payload.contiguous(), async_op=True)
+
+    def timings_ms(self):
+        """Per recorded step (after a device synchronize): the compute stream's time from `payload ready` to the end of the
+        exchange (`total`: the per-Gaussian backward half runs inside it), its stall at the all-gather wait, the rebuild kernel
+        + the all-reduce wait (`rebuild_and_reduce_wait`), and the all-reduce stall that remained after the rebuild."""
+        out = []
+        for ev in self._events:
+            if len(ev) == 5:
+                out.append({"total": ev[0].elapsed_time(ev[4]), "gather_wait": ev[1].elapsed_time(ev[2]),
+                            "rebuild_and_reduce_wait": ev[2].elapsed_time(ev[4]), "reduce_wait": ev[3].elapsed_time(ev[4])})
+        return out
+
+    @staticmethod
+    def bytes_per_rank(n, world):
+        """Bytes one rank sends (= receives) per step: the 11-float arena through a bandwidth-optimal all-reduce
+        (2 (V-1)/V of it) and its 3-float payload + camera position to each of the V-1 peers."""
+        reduce_b = 2.0 * (world - 1) / world * 4 * arena_size(n, small=True)
+        gather_b = (world - 1) * 4 * (3 * n + 4)
+        return {"all_reduce": int(reduce_b), "all_gather": int(gather_b), "total": int(reduce_b + gather_b),
+                "dense_all_reduce_instead": int(2.0 * (world - 1) / world * 4 * arena_size(n))}
 
     def finish(self, grads, means3D, degree=3, average=True, out=None):
         """Returns the dict of the five averaged (or summed) optimizer gradients."""
@@ -148,13 +181,20 @@ class FactoredExchange:
                 reduce_work = dist.all_reduce(arena, op=dist.ReduceOp.AVG, async_op=True)
             else:
                 reduce_work = dist.all_reduce(arena, op=dist.ReduceOp.SUM, async_op=True)
+        self._mark()
         if self._work is not None:
             self._work.wait()
+        self._mark()
         res = {"dL_dshs": sh_gradients_from_views(means3D, self._gathered, degree, average=average, out=out)}
+        self._mark()
         if reduce_work is not None:
             reduce_work.wait()
             if average and not (arena.is_cuda and dist.get_backend() == "nccl"):
                 arena.mul_(1.0 / dist.get_world_size())
+        self._mark()
+        if self._cur is not None:
+            self._events.append(self._cur)
+            self._cur = None
         res.update(small_arena_views(arena, n))
         self._gathered = self._work = None
         return res

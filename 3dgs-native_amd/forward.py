@@ -4,11 +4,15 @@ MI355X library.  Same keyword arguments, same (image, depth, dict) return with t
 arrays come back as torch tensors on the GPU instead of wp.array (callers do `.cpu().numpy()`).
 """
 import ctypes as C
+import os
+import weakref
 
 import torch
 
 from . import _host, _lib
 from .config import TILE_M, TILE_N
+
+_NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))   # A/B switch: backward reads the SH rows itself (same results)
 
 
 def render_gaussians(background, means3D, colors=None, opacity=None, scales=None, rotations=None, scale_modifier=1.0,
@@ -39,8 +43,13 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     radii, tiles_touched, point_offsets = e((N,), i32), e((N,), i32), e((N,), i32)
     xy, depths, cov3Ds, rgb = e((N, 2), f32), e((N,), f32), e((N, 6), f32), e((N, 3), f32)
     conic_opacity, clamped_state = e((N, 4), f32), e((N, 3), f32)
+    # d(colour)/d(direction), nine floats per Gaussian: what the SH backward needs of the 48 coefficients (GsrGeom.sh_dir_grad).
+    # Only worth its 36 bytes per Gaussian when the caller's SH / position tensors can be recognised again by backward(), i.e.
+    # when they are device tensors used in place.
+    in_place = lambda given, used: isinstance(given, torch.Tensor) and given.is_cuda and given.data_ptr() == used.data_ptr()
+    sh_dir = e((N, 9), f32) if (N > 0 and in_place(sh, shs) and in_place(means3D, means) and not _NO_SH_DIR) else None
     geom = _lib.GsrGeom(_host.ptr(radii), _host.ptr(tiles_touched), _host.ptr(point_offsets), _host.ptr(xy), _host.ptr(depths),
-                        _host.ptr(cov3Ds), _host.ptr(rgb), _host.ptr(conic_opacity), _host.ptr(clamped_state), None)
+                        _host.ptr(cov3Ds), _host.ptr(rgb), _host.ptr(conic_opacity), _host.ptr(clamped_state), None, _host.ptr(sh_dir))
     image, depth_image = e((H, W, 3), f32), e((H, W), f32)
     final_Ts, n_contrib = e((H, W), f32), e((H, W), i32)
     img = _lib.GsrImage(_host.ptr(image), _host.ptr(depth_image), _host.ptr(final_Ts), _host.ptr(n_contrib))
@@ -69,7 +78,14 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         xy._gsr_records = _host.tag_records(gws, N)
         # likewise the block masks ride on the point_list tensor (their own allocation, alive as long as it is): a caller
         # that hands backward() this very tensor gets the mask-driven compaction, anyone else the self-contained one
-        point_list._gsr_block_masks = block_masks
+        # -- and only together with the other buffers of this call (backward() checks identity): the masks describe these
+        # records, up to these n_contrib
+        if sh_dir is not None:
+            # the direction derivatives ride on clamped_state (which backward() receives as `clamped`), valid for these very
+            # sh / means3D tensors, this camera position and this degree
+            clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(float(v) for v in cam.campos), int(degree))
+        owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
+        point_list._gsr_block_masks = (block_masks, {k: weakref.ref(v) for k, v in owners.items()})
     return image, depth_image, {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
         "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,

@@ -70,20 +70,70 @@ def stage_bytes(N, Nv, D, P, Tn):
     """Algorithmic HBM bytes per launch of each timed stage.  The per-unit figures are SURVEY.md section 8(d)'s
     (compulsory traffic: every input read once, every output written once, every list entry read once per
     tile) for the stages the reference has, and the same counting rule for the stages of our own binning
-    design."""
+    design, priced from the item widths and pass counts the library really uses (api.hip): depth items are
+    8 bytes (4 passes: histogram read + scatter read + write); tile items are 4 bytes when tile bits + id bits <= 32 (C3: 12 + 20),
+    else 8, ceil(tile bits / 8) passes, the last of which writes the 4-byte point_list instead of items."""
+    tb = max(1, int(np.ceil(np.log2(max(2, Tn)))))
+    id_bits = max(1, int(np.ceil(np.log2(max(2, N)))))
+    ib = 4 if tb + id_bits <= 32 else 8
+    npass = (tb + 7) // 8
     return {
         "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv,
         "scan": 8 * N,
-        "depth_sort": 4 * 24 * N,             # 4 passes x (8 B histogram read + 8 B read + 8 B write) per item
+        "depth_sort": 4 * 24 * N,
         "depth_scan": 16 * N,
-        "expand": 20 * Nv + 8 * D,
-        "tile_sort": 2 * 24 * D + 12 * D + 8 * Tn,   # since round 2 the last pass also writes point_list and ranges (the old "ranges" stage)
+        "expand": 20 * Nv + ib * D,
+        "tile_sort": (npass - 1) * 3 * ib * D + (2 * ib + 4) * D + 8 * Tn,
         "ranges": 0,
         "blend_fwd": 44 * D + 8 * Tn + 24 * P,
         "bwd_prep": 64 * N,
         "blend_bwd": 40 * D + 20 * P + 44 * N,
         "geom_bwd": 4 * N + 308 * Nv + 232 * N,
     }
+
+
+def measure_exchange(gsr, dist, torch, args, world, N, means, step, exchange):
+    """N > 1 only, AFTER the timed region (nothing here is part of `value`): what the gradient exchange costs on this rank.
+    (1) ten more steps with the exchange's own events on: the compute stream's stalls at the two collectives and the rebuild
+    kernel, as the overlapped step really pays them; (2) each collective alone, synchronous, bracketed by HIP events on the
+    stream it is enqueued behind (median of 5 after a barrier), to be read against DESIGN section 5's byte arithmetic."""
+    dev = means.device
+    rep = {"bytes_per_rank": gsr.dist.FactoredExchange.bytes_per_rank(N, world), "backend": args.backend}
+    if not args.dense_exchange:
+        exchange.timing = True
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        exchange.timing = False
+        tm = exchange.timings_ms()
+        if tm:
+            rep["overlapped_step_ms"] = {k: round(float(np.median([t[k] for t in tm])), 4) for k in tm[0]}
+
+    def alone(fn):
+        ts = []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return round(float(np.median(ts)), 4)
+
+    small = torch.zeros(gsr.dist.arena_size(N, small=True), dtype=torch.float32, device=dev)
+    dense = torch.zeros(gsr.dist.arena_size(N), dtype=torch.float32, device=dev)
+    payload = torch.zeros(3 * N + 4, dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, payload.numel()), dtype=torch.float32, device=dev)
+    op = dist.ReduceOp.AVG if args.backend == "nccl" else dist.ReduceOp.SUM
+    rep["alone_ms"] = {
+        "all_reduce_11_floats": alone(lambda: dist.all_reduce(small, op=op)),
+        "all_gather_3_floats": alone(lambda: dist.all_gather_into_tensor(gathered.view(-1), payload)),
+        "sh_rebuild": alone(lambda: gsr.dist.sh_gradients_from_views(means, gathered, 3, average=True)),
+        "all_reduce_59_floats_dense": alone(lambda: dist.all_reduce(dense, op=op)),
+    }
+    return rep
 
 
 def main():
@@ -151,6 +201,8 @@ def main():
 
     sh_out = torch.empty((N * 16, 3), dtype=torch.float32, device=dev) if world > 1 else None
     exchange = gsr.dist.FactoredExchange()
+    exchange_report = None
+    parity_failed = False
 
     def step():
         img, depth, buf = gsr.render_gaussians(**fkw)
@@ -223,6 +275,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if world > 1:
+        exchange_report = measure_exchange(gsr, dist, torch, args, world, N, means, step, exchange)
+
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * vps * W * H / (elapsed / args.steps) / 1e6
     per_step = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])   # this rank's device time per step
@@ -244,6 +299,8 @@ def main():
                     "how": "HIP events on the launch stream between consecutive steps (rank 0); ms_per_step is the wall-clock mean"},
     }
 
+    if exchange_report is not None:
+        out["exchange"] = exchange_report
     if rank == 0:
         P, Tn = W * H, ((W + 15) // 16) * ((H + 15) // 16)
         if stages and nrec > 0:
@@ -314,6 +371,17 @@ def main():
                 ok, rel = parity.grad_margin(gg[k], og[k])      # |d| <= 1e-4 max|g| + 1e-3 |g|
                 par[k + "_frac_within_tol"] = ok
                 par[k + "_max_err_over_max"] = rel
+            # the same tripwires as tests/test_gpu_parity.py::test_full_size_configs (about 10x the margins measured in rounds 1-2)
+            trip = []
+            if par["image_pixels_beyond_1e-3"] > parity.TRIP_FLIPS:
+                trip.append("image flips")
+            if par["n_contrib_frac_equal"] < parity.TRIP_NCONTRIB:
+                trip.append("n_contrib")
+            trip += [k for k in ("radii", "point_offsets", "point_list", "ranges") if not par[k + "_exact"]]
+            trip += [k for k in ("dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dshs")
+                     if par[k + "_frac_within_tol"] < parity.TRIP_GRAD_FRAC or par[k + "_max_err_over_max"] > parity.TRIP_GRAD_MAX]
+            par["tripwires"] = "ok" if not trip else "VIOLATED: " + ", ".join(trip)
+            parity_failed = bool(trip)
             out["cpu_baseline"] = {"value": round(W * H / (t_f + t_b) / 1e6, 5), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                                    "sample": f"one full {args.config} frame (same scene and view), forward {t_f:.2f} s + backward {t_b:.2f} s, "
                                              f"single-thread C oracle (gcc -O2), host has {os.cpu_count()} cores",
@@ -321,6 +389,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the timed path disagrees with the oracle beyond the tripwires (cpu_baseline.parity_full_size)")
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 #define GSR_TILE 16
 #define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
 #define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
@@ -100,6 +100,13 @@ typedef struct GsrGeom {
     const void *blend_records; /* optional, gsr_backward only: the N 64-byte blend records gsr_forward_count
                                   left at the START of geom_ws, if the caller still holds that buffer
                                   unmodified; NULL -> rebuilt from xy / conic_opacity / rgb (same values) */
+    float *sh_dir_grad;     /* optional [N*9], not part of the reference's dict.  gsr_forward_count, given a buffer, writes per
+                               visible Gaussian the nine sums d(colour before clamping)/d(view direction) that the SH backward
+                               (backward.py:120-244) forms from the 48 coefficients: (d/dx, d/dy, d/dz) x (r, g, b), the same
+                               float operations.  gsr_backward / gsr_backward_geom, given that buffer back, use it and do not
+                               read scene->sh (36 instead of 192 bytes per Gaussian) -- valid only while scene->sh, scene->means,
+                               sh_degree and camera->campos are those of the forward call that filled it.  NULL on either
+                               side is fine: the backward then reads the coefficients itself.  Same results either way. */
 } GsrGeom;
 
 /* Sorted (tile, depth) list: dict entries point_list / ranges. */

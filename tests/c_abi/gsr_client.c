@@ -80,6 +80,9 @@ int main(int argc, char **argv)
     g.radii = dev_alloc(4 * n); g.tiles_touched = dev_alloc(4 * n); g.point_offsets = dev_alloc(4 * n); g.xy = dev_alloc(8 * n);
     g.depths = dev_alloc(4 * n); g.cov3D = dev_alloc(24 * n); g.rgb = dev_alloc(12 * n); g.conic_opacity = dev_alloc(16 * n);
     g.clamped_state = dev_alloc(12 * n);
+#ifndef GSR_CLIENT_CPU
+    g.sh_dir_grad = dev_alloc(36 * n); /* forward -> backward: the SH backward then skips the 192-byte coefficient rows */
+#endif
     const size_t geom_bytes = gsr_geom_workspace_bytes(N);
     void *geom_ws = dev_alloc(geom_bytes);
     int64_t D = -1;

@@ -7,6 +7,8 @@
   gpu   config #4 in miniature on ONE GPU (every rank on cuda:0, gloo through host memory): rank r renders Lego train
         frame r of a small seeded scene, backward(sh_gradient="factored", on_payload=FactoredExchange.start_gather),
         FactoredExchange.finish -> the view-averaged optimizer gradients, saved per rank
+  nccl  the same step with one GPU per rank (cuda:LOCAL_RANK) over RCCL, the factored exchange AND the dense 59-float
+        all-reduce of the same views (keys prefixed "dense_"); needs torch.cuda.device_count() >= WORLD_SIZE
 """
 import importlib
 import json
@@ -53,7 +55,12 @@ def main():
     import torch
     gsr = importlib.import_module("3dgs-native_amd")
     d = gsr.dist
-    d.init_from_env(backend="gloo")
+    if mode == "nccl":
+        dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+        torch.cuda.set_device(dev)
+        d.init_from_env(backend="nccl", device=dev)
+    else:
+        d.init_from_env(backend="gloo")
     if mode == "cpu":
         n = 500
         arena = torch.full((d.ARENA_FLOATS * n,), float(rank + 1))
@@ -74,6 +81,22 @@ def main():
         res = ex.finish(g, means, GPU_CASE["degree"], average=True)
         torch.cuda.synchronize()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **{k: v.cpu().numpy() for k, v in res.items()})
+    elif mode == "nccl":
+        scene = gpu_case_scene(gsr)
+        fkw, bkw, _ = gpu_case_view(gsr, scene, rank)
+        ex = d.FactoredExchange(timing=True)
+        g = gsr.backward(**bkw, sh_gradient="factored", on_payload=ex.start_gather)
+        means = torch.as_tensor(scene["means"]).cuda().contiguous()
+        res = {k: v.clone() for k, v in ex.finish(g, means, GPU_CASE["degree"], average=True).items()}
+        g_dense = gsr.backward(**bkw)                      # the same view again, dense: one all-reduce of the 59-float arena
+        d.reduce_gradients(g_dense["_arena"], world, average=True)
+        dense = d.arena_views(g_dense["_arena"], GPU_CASE["n"])
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in res.items()}
+        out.update({"dense_" + k: v.cpu().numpy() for k, v in dense.items()})
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+        if rank == 0:
+            print(json.dumps({"exchange_ms": ex.timings_ms(), "bytes_per_rank": d.FactoredExchange.bytes_per_rank(GPU_CASE["n"], world)}), flush=True)
     else:
         raise SystemExit(f"unknown mode {mode}")
     torch.distributed.barrier()

@@ -106,6 +106,25 @@ def test_needle_splats_against_both_checkers(oracle, cameras, scenes, seed):
         # elements outside: at most those the float32 rounding puts outside plus those the summation order does (union bound)
         assert standard or (e_g <= 6.0 * yard + 1e-6 and (1.0 - ok_g) <= (1.0 - ok_o) + (1.0 - ok_s) + slack), \
             f"{k}: kernel {ok_g:.5f} inside / max {e_g:.2e}, float32 reference order {ok_o:.5f} / {e_o:.2e}, run-to-run {ok_s:.5f} / {spread:.2e}"
+    # The criterion above is FROZEN as of round 3 (it was relaxed three times in round 2 until green).  What the
+    # kernel measured when it was frozen is committed in tests/golden/needle_margins.json (one row per seed and array); a later
+    # change that moves an array's error beyond 3x its recorded value (+ the run-to-run spread recorded beside it), or puts
+    # visibly more elements outside the tight band, fails here even if the criterion above would still let it pass.
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "needle_margins.json")
+    rec_path = os.environ.get("GSR_NEEDLE_RECORD")
+    if rec_path:
+        import json
+        with open(rec_path, "a") as f:
+            f.write(json.dumps({"seed": seed, "rows": [[r[0]] + [float(x) for x in r[1:]] for r in rows]}) + "\n")
+    elif os.path.exists(gold_path) and NEEDLE_CASES <= 12:
+        import json
+        with open(gold_path) as f:
+            gold = {g["seed"]: {r[0]: r[1:] for r in g["rows"]} for g in json.load(f)["cases"]}
+        for k, ok_g, e_g, ok_o, e_o, spread in rows:
+            g_ok, g_e, _, _, g_spread = gold[seed][k]
+            n_el = max(1, parity.to_np(g1[k]).size)
+            assert e_g <= 3.0 * max(g_e, g_spread) + 2e-5, f"{k}: max error {e_g:.2e} vs {g_e:.2e} (spread {g_spread:.2e}) when the criterion was frozen"
+            assert (1.0 - ok_g) <= 3.0 * (1.0 - g_ok) + max(5e-3, 4.0 / n_el), f"{k}: {ok_g:.5f} inside vs {g_ok:.5f} when the criterion was frozen"
     if seed == 0 or os.environ.get("GSR_FUZZ_VERBOSE"):
         print(f"\nneedle case {seed} ({W}x{H}): array, kernel [frac inside, max err/max|g|] vs f64-accumulated; float32 reference order likewise; kernel run-to-run")
         for r in rows:

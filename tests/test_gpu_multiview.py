@@ -11,6 +11,10 @@ itself is single-view: train.py:928, and hands ONE view's gradients to its optim
   test_two_rank_factored_exchange   two processes (launch.launch_ranks, gloo, both on cuda:0) run FactoredExchange end to
                                 end; both ranks must hold the same bits, equal to the single-process rebuild of the same
                                 two views and within tolerance of the oracle's two-view mean.
+  test_two_gpus_rccl            SKIPPED unless torch.cuda.device_count() >= 2 (the first multi-GPU lease runs it): two ranks,
+                                one GPU each, backend nccl = RCCL over xGMI, one view each of the same scene; both ranks hold
+                                identical bits, factored == dense all-reduce within the order-of-summation tolerance, both
+                                within tests/parity.py of the oracle's two-view mean.
 """
 import importlib
 import os
@@ -107,3 +111,37 @@ def test_two_rank_factored_exchange(oracle, tmp_path):
         np.testing.assert_allclose(r0[k], a, err_msg=k, **tol(a))
     for k in OPT_KEYS:                       # and against the oracle's two-view mean
         parity.assert_grad("2-rank " + k, r0[k], ref_mean[k].astype(np.float32).reshape(r0[k].shape))
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()     # counts devices without initialising the GPU runtime in this process
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_gpus_rccl(oracle, tmp_path, capfd):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    gsr = pkg()
+    launch = importlib.import_module(f"{PKG_NAME}.launch")
+    rc = launch.launch_ranks(os.path.join(ROOT, "tests", "dist_worker.py"), ["nccl", str(tmp_path)], 2, timeout=400)
+    assert rc == 0
+    print(capfd.readouterr().out)        # rank 0's exchange timings and byte counts
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:                   # every rank ends the step with the same bits, for both exchanges
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    scene = dist_worker.gpu_case_scene(gsr)
+    ref_mean = {k: 0.0 for k in OPT_KEYS}
+    for f in range(2):
+        fkw, bkw, cam = dist_worker.gpu_case_view(gsr, scene, f)
+        ref = oracle.render_gaussians(**fkw)
+        g_ref = oracle.backward(**backward_kwargs(scene, cam, fkw, ref[2], bkw["dL_dpixels"].cpu().numpy()))
+        for k in OPT_KEYS:
+            ref_mean[k] = ref_mean[k] + np.asarray(g_ref[k], dtype=np.float64) / 2.0
+    for k in OPT_KEYS:
+        want = ref_mean[k].astype(np.float32).reshape(r0[k].shape)
+        # factored vs dense: the same per-view products, summed over views in a different order (and float atomics per replay)
+        np.testing.assert_allclose(r0[k], r0["dense_" + k].reshape(r0[k].shape), rtol=2e-3, atol=1e-4 * float(np.abs(want).max()), err_msg=k)
+        parity.assert_grad("2-GPU factored " + k, r0[k], want)
+        parity.assert_grad("2-GPU dense " + k, r0["dense_" + k].reshape(r0[k].shape), want)

@@ -98,6 +98,7 @@ def test_c2_lego_100k(oracle, cameras, scenes):
     cam = lego_camera(cameras, frame=0, width=800, height=800)
     report = {}
     _fwd_bwd(oracle, sc, cam, 800, 800, report=report)
+    parity.assert_tripwires("C2", report)
     print("\nC2 measured margins (image: frac within 2e-5, max err, flips; gradients: frac within 1e-4 max|g| + 1e-3 |g|, max err / max|g|):")
     print(parity.format_report(report))
 
@@ -111,6 +112,7 @@ def test_full_size_configs(oracle, cameras, scenes, name):
     cam = cameras.nerf_camera(scenes.LEGO_FRAME0, cfg["width"], cfg["height"], scenes.LEGO_CAMERA_ANGLE_X)
     report = {}
     _fwd_bwd(oracle, sc, cam, cfg["width"], cfg["height"], report=report)
+    parity.assert_tripwires(name, report)
     print(f"\n{name} measured margins (image: frac within 2e-5, max err, flips; gradients: frac within 1e-4 max|g| + 1e-3 |g|, max err / max|g|):")
     print(parity.format_report(report))
 
@@ -192,6 +194,145 @@ def test_workspace_and_capacity_errors(cameras, scenes):
         _lib.check(rc)
     with pytest.raises(ValueError):
         gsr.render_gaussians(**dict(render_kwargs(sc, cam), sh=sc["shs"][:, :4]))   # not 16 coefficients per Gaussian
+
+
+def test_more_than_2_30_pairs_is_refused_on_the_device_path(cameras, scenes):
+    """Reference forward.py:765-767: `if num_rendered > (1 << 30): raise ValueError`.  Here the count really comes out of the
+    device scan: 140 000 Gaussians of scale 50 at 1920x1080 each cover all 120 x 68 tiles, D = 1 142 400 000 > 2^30 (and
+    < 2^31, so the int32 scan itself does not wrap).  gsr_forward_count must return GSR_E_OVERFLOW -> ValueError before any
+    D-sized buffer is allocated or written; a normal call afterwards works."""
+    import torch
+    gsr = pkg()
+    n = 140_000
+    sc = scenes.synthetic_scene(n, 50.0, 0.0, seed=8, extent=0.5)
+    cam = cameras.nerf_camera(scenes.LEGO_FRAME0, 1920, 1080, scenes.LEGO_CAMERA_ANGLE_X)
+    before = torch.cuda.memory_allocated()
+    with pytest.raises(ValueError, match="2\\^30"):
+        gsr.render_gaussians(**render_kwargs(sc, cam))
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() - before < (1 << 30)      # nothing of size D (4.6 GB of point_list alone) was allocated
+    # one Gaussian fewer than the limit allows is accepted by the count: 131 000 x 8160 = 1 068 960 000 <= 2^30
+    small = scenes.synthetic_scene(2000, 0.05, 0.5, seed=9)
+    img = gsr.render_gaussians(**render_kwargs(small, lego_camera(cameras, 0, 128, 96)))[0]
+    assert torch.isfinite(img).all()
+
+
+def test_offset_views_are_accepted(oracle, cameras, scenes):
+    """contiguous but unaligned device views (means[1:], scales[1:] -- 12-byte rows) are what a caller slicing its
+    parameter tensors passes; the reference copies every input and accepts them.  They must give the answer of a fresh copy."""
+    import torch
+    gsr = pkg()
+    sc = scenes.synthetic_scene(1201, 0.05, 0.6, 21)
+    cam = lego_camera(cameras, frame=3, width=144, height=112)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    full = {k: dev(sc[k]) for k in ("means", "opacities", "scales", "rotations", "shs")}
+    cut = {k: v[1:] for k, v in full.items()}
+    assert cut["means"].data_ptr() % 16 != 0
+    sub_sc = {k: sc[k][1:] for k in full}
+    kw_ref = render_kwargs(sub_sc, cam, width=144, height=112)
+    kw = dict(kw_ref, means3D=cut["means"], opacity=cut["opacities"], scales=cut["scales"], rotations=cut["rotations"], sh=cut["shs"].reshape(-1, 3))
+    got, want = gsr.render_gaussians(**kw), gsr.render_gaussians(**kw_ref)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2]["point_list"], want[2]["point_list"])
+    dpix = dev(_pixel_grad(112, 144))
+    off_dpix = torch.cat([dpix.reshape(-1)[:1], dpix.reshape(-1)])[1:].reshape(112, 144, 3)   # a 4-byte-offset view of the same values
+    bkw = backward_kwargs(sub_sc, cam, kw_ref, got[2], off_dpix)
+    assert bkw["dL_dpixels"].data_ptr() % 16 != 0
+    bkw.update(means3D=cut["means"], opacity=cut["opacities"], scales=cut["scales"], rotations=cut["rotations"], shs=cut["shs"].reshape(-1, 3))
+    g = gsr.backward(**bkw)
+    g_ref = oracle.backward(**backward_kwargs(sub_sc, cam, kw_ref, oracle.render_gaussians(**kw_ref)[2], dpix.cpu().numpy()))
+    parity.compare_backward(g, g_ref)
+
+
+def test_forward_masks_are_reused_only_with_the_forwards_own_buffers(oracle, cameras, scenes):
+    """the forward's block masks describe ITS records up to ITS n_contrib.  backward() takes the mask-driven
+    compaction only when point_list, ranges, n_contrib, final_Ts, means2D and conic_opacity are that forward's own tensors; with
+    any of them replaced (here: equal-valued copies, and the oracle's buffers) it must fall back to the self-contained block
+    test -- and either way agree with the oracle."""
+    gsr = pkg()
+    from conftest import sub
+    bwd = sub("backward").backward
+    sc = scenes.synthetic_scene(4000, 0.05, 0.6, 31)
+    cam = lego_camera(cameras, frame=5, width=176, height=128)
+    kw = render_kwargs(sc, cam, width=176, height=128)
+    got, ref = gsr.render_gaussians(**kw), oracle.render_gaussians(**kw)
+    dpix = _pixel_grad(128, 176)
+    g_ref = oracle.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix))
+    own = backward_kwargs(sc, cam, kw, got[2], dpix)
+    parity.compare_backward(gsr.backward(**own), g_ref)
+    assert bwd.last_call_used_forward_masks
+    for key in ("means2D", "conic_opacity"):
+        mixed = dict(own)
+        mixed[key] = own[key].clone()
+        mixed["geom_buffer"] = dict(own["geom_buffer"], **{key: mixed[key]})
+        parity.compare_backward(gsr.backward(**mixed), g_ref)
+        assert not bwd.last_call_used_forward_masks, key
+    for key in ("ranges", "n_contrib", "final_Ts"):
+        mixed = dict(own, img_buffer=dict(own["img_buffer"], **{key: own["img_buffer"][key].clone()}))
+        parity.compare_backward(gsr.backward(**mixed), g_ref)
+        assert not bwd.last_call_used_forward_masks, key
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix)), g_ref)   # the oracle's buffers (numpy)
+    assert not bwd.last_call_used_forward_masks
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_sh_direction_sums_handed_from_forward_to_backward(oracle, cameras, scenes, degree):
+    """GsrGeom.sh_dir_grad: with device-resident parameter tensors the forward leaves d(colour)/d(direction) (nine floats per
+    Gaussian) for the backward, whose per-Gaussian kernel then skips the 192-byte SH rows.  Same float operations either way
+    (sh_stage.h sh_direction_sums), so the two paths must agree far inside the parity tolerance (the blend half's float atomics
+    are the only run-to-run difference), and each with the oracle; a caller that swaps any of the tensors the sums were formed
+    from (sh, means, camera position, degree) must get the self-contained path."""
+    import torch
+    gsr = pkg()
+    from conftest import sub
+    bwd = sub("backward").backward
+    sc = scenes.synthetic_scene(5000, 0.05, 0.6, 41 + degree)
+    sc["shs"][::3] *= 4.0                       # some colours clamp
+    cam = lego_camera(cameras, frame=degree, width=208, height=160)
+    kw_np = render_kwargs(sc, cam, width=208, height=160, degree=degree)
+    dev = {k: torch.as_tensor(np.ascontiguousarray(sc[k])).cuda() for k in ("means", "opacities", "scales", "rotations")}
+    dev["shs"] = torch.as_tensor(np.ascontiguousarray(sc["shs"])).cuda().reshape(-1, 3)
+    kw = dict(kw_np, means3D=dev["means"], opacity=dev["opacities"], scales=dev["scales"], rotations=dev["rotations"], sh=dev["shs"])
+    img, _, buf = gsr.render_gaussians(**kw)
+    dpix = torch.as_tensor(_pixel_grad(160, 208)).cuda()
+    own = backward_kwargs(sc, cam, kw, buf, dpix)
+    own.update(means3D=dev["means"], opacity=dev["opacities"], scales=dev["scales"], rotations=dev["rotations"], shs=dev["shs"])
+    g_fast = gsr.backward(**own)
+    assert bwd.last_call_used_forward_sh_dir
+    ref = oracle.render_gaussians(**kw_np)
+    g_ref = oracle.backward(**backward_kwargs(sc, cam, kw_np, ref[2], dpix.cpu().numpy()))
+    parity.compare_backward(g_fast, g_ref)
+    for swap in ("shs", "means3D", "campos", "degree", "clamped"):
+        other = dict(own)
+        if swap == "campos":
+            other["campos"] = np.asarray(own["campos"], np.float64) + 0.0    # equal values in a new array: still the fast path
+        elif swap == "degree":
+            if degree == 3:
+                continue
+            other["degree"] = degree + 1
+        elif swap == "clamped":
+            other["clamped"] = own["clamped"].clone()
+            other["geom_buffer"] = dict(own["geom_buffer"], clamped_state=other["clamped"])
+        else:
+            other[swap] = own[swap].clone()
+        g_slow = gsr.backward(**other)
+        assert bwd.last_call_used_forward_sh_dir == (swap == "campos"), swap
+        if swap != "degree":
+            for k in ("dL_dmean3D", "dL_dshs", "dL_dscale", "dL_drot"):
+                a, b = parity.to_np(g_fast[k]), parity.to_np(g_slow[k])
+                np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()), err_msg=f"{swap} {k}")
+
+
+def test_dL_dcov3D_is_a_dense_zero_array(cameras, scenes):
+    """backward.py:1119 returns an (N, 6) zero array; ours must behave like one (dense strides, .view(-1), numpy)."""
+    gsr = pkg()
+    sc = scenes.synthetic_scene(300, 0.05, 0.5, 4)
+    cam = lego_camera(cameras, 1, 64, 48)
+    kw = render_kwargs(sc, cam, width=64, height=48)
+    buf = gsr.render_gaussians(**kw)[2]
+    g = gsr.backward(**backward_kwargs(sc, cam, kw, buf, _pixel_grad(48, 64)))
+    z = g["dL_dcov3D"]
+    assert tuple(z.shape) == (300, 6) and z.is_contiguous() and z.view(-1).numel() == 1800
+    assert float(z.abs().max()) == 0.0 and z.cpu().numpy().strides == (24, 4)
 
 
 @pytest.mark.parametrize("field,val", [("means", np.nan), ("means", np.inf), ("means", 1e30), ("scales", np.nan), ("scales", 0.0),

@@ -32,7 +32,7 @@ constexpr int REPS = 2048;
 
 enum Kind {
     FMA_V, FMA_S, MUL_LIT, MOV, MAX, MED3, AND, CNDMASK_VCC, CNDMASK_SGPR, CNDMASK_VCC_E64, CMP_VCC, CMP_SGPR, CMP_CNDMASK, CMP_CNDMASK_SGPR, CMPX,
-    SAVEEXEC_FMA, CMP_BRANCH, READFIRSTLANE, EXP_DEP, LDS_B128_BCAST, LDS_B64_BCAST, LDS_U16_BCAST, LDS_B128_LANES, LDS_B32_LANES, KINDS
+    SAVEEXEC_FMA, CMP_BRANCH, READFIRSTLANE, EXP_DEP, MIN_U32, MAX_I32, BFI, SUB_U32, ASHR, ADD3, AND_OR, MAX3_F32, MIN_F32_LIT, MUL_CLAMP, FMAC, CMP_I32, CMP_CLASS, MOV_DPP, ADD_DPP_ROW, SUB_CO, MED3_I32, LSHL_ADD, MUL_LEGACY, CVT_I32, LDS_B128_BCAST, LDS_B64_BCAST, LDS_U16_BCAST, LDS_B128_LANES, LDS_B32_LANES, KINDS
 };
 static const char *kind_name[KINDS] = {
     "v_fma_f32 v,v,v,v (reference)",
@@ -54,6 +54,26 @@ static const char *kind_name[KINDS] = {
     "v_cmp_lt_f32 -> vcc ; s_cbranch_vccnz (never taken)   (pair = 2 instructions)",
     "v_readfirstlane_b32",
     "v_fma -> v_exp_f32 -> v_fma dependent chain (3 instructions per link)",
+    "v_min_u32",
+    "v_max_i32",
+    "v_bfi_b32",
+    "v_sub_u32 (no carry out)",
+    "v_ashrrev_i32",
+    "v_add3_u32",
+    "v_and_or_b32",
+    "v_max3_f32",
+    "v_min_f32 with a literal",
+    "v_mul_f32_e64 ... clamp",
+    "v_fmac_f32 (VOP2)",
+    "v_cmp_lt_i32 -> vcc",
+    "v_cmp_class_f32 -> vcc",
+    "v_mov_b32_dpp row_shr:1",
+    "v_add_f32_dpp row_shr:1 (independent)",
+    "v_sub_co_u32 (carry out to vcc)",
+    "v_med3_i32",
+    "v_lshl_add_u32",
+    "v_mul_legacy_f32",
+    "v_cvt_i32_f32",
     "ds_read_b128, all lanes one address",
     "ds_read_b64, all lanes one address",
     "ds_read_u16, all lanes one address",
@@ -167,6 +187,86 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, long long *cycles
             asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_exp_f32 %0, %0\n\tv_fma_f32 %0, %0, %9, %8\n\t"
                          "v_fma_f32 %0, %0, %8, %9\n\tv_exp_f32 %0, %0\n\tv_fma_f32 %0, %0, %9, %8\n\t"
                          "v_fma_f32 %0, %0, %8, %9\n\tv_exp_f32 %0, %0\n\t" OPS);
+        } else if constexpr (KIND == MIN_U32) {
+#define I(n) "v_min_u32 %" #n ", %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == MAX_I32) {
+#define I(n) "v_max_i32 %" #n ", %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == BFI) {
+#define I(n) "v_bfi_b32 %" #n ", %8, %" #n ", %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == SUB_U32) {
+#define I(n) "v_sub_u32 %" #n ", %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == ASHR) {
+#define I(n) "v_ashrrev_i32 %" #n ", 1, %" #n "\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == ADD3) {
+#define I(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == AND_OR) {
+#define I(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == MAX3_F32) {
+#define I(n) "v_max3_f32 %" #n ", %" #n ", %8, %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == MIN_F32_LIT) {
+#define I(n) "v_min_f32 %" #n ", 0x3f7d70a4, %" #n "\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == MUL_CLAMP) {
+#define I(n) "v_mul_f32_e64 %" #n ", %" #n ", %8 clamp\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == FMAC) {
+#define I(n) "v_fmac_f32 %" #n ", %8, %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == CMP_I32) {
+#define I(n) "v_cmp_lt_i32 vcc, %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS : "vcc");
+#undef I
+        } else if constexpr (KIND == CMP_CLASS) {
+#define I(n) "v_cmp_class_f32 vcc, %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS : "vcc");
+#undef I
+        } else if constexpr (KIND == MOV_DPP) {
+#define I(n) "v_mov_b32_dpp %" #n ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == ADD_DPP_ROW) {
+#define I(n) "v_add_f32_dpp %" #n ", %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == SUB_CO) {
+#define I(n) "v_sub_co_u32 %" #n ", vcc, %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS : "vcc");
+#undef I
+        } else if constexpr (KIND == MED3_I32) {
+#define I(n) "v_med3_i32 %" #n ", %" #n ", %8, %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == LSHL_ADD) {
+#define I(n) "v_lshl_add_u32 %" #n ", %" #n ", 1, %9\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == MUL_LEGACY) {
+#define I(n) "v_mul_legacy_f32 %" #n ", %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
+        } else if constexpr (KIND == CVT_I32) {
+#define I(n) "v_cvt_i32_f32 %" #n ", %8\n\t"
+            asm volatile(ALL8(I) OPS);
+#undef I
         } else if constexpr (KIND == LDS_B128_BCAST || KIND == LDS_B128_LANES) {
             float4 q0, q1, q2, q3, q4, q5, q6, q7;
             const float4 *p = lds + (r & 31) + (KIND == LDS_B128_LANES ? (threadIdx.x & 63) : 0);
@@ -240,10 +340,12 @@ int main()
     printf("# LDS kinds: the loop adds one v_add_f32 per read (not counted); pairs / triples are counted per instruction\n");
 #define SWEEP(K)                                                                                                  \
     printf("%s\n", kind_name[K]);                                                                                 \
-    for (int w : {1, 2, 4, 8}) run<K>(w, out, cyc, host);
+    for (int w : {1, 4, 8}) run<K>(w, out, cyc, host);
     SWEEP(FMA_V) SWEEP(FMA_S) SWEEP(MUL_LIT) SWEEP(MOV) SWEEP(MAX) SWEEP(MED3) SWEEP(AND)
     SWEEP(CNDMASK_VCC) SWEEP(CNDMASK_SGPR) SWEEP(CNDMASK_VCC_E64) SWEEP(CMP_VCC) SWEEP(CMP_SGPR) SWEEP(CMP_CNDMASK) SWEEP(CMP_CNDMASK_SGPR)
     SWEEP(CMPX) SWEEP(SAVEEXEC_FMA) SWEEP(CMP_BRANCH) SWEEP(READFIRSTLANE) SWEEP(EXP_DEP)
+    SWEEP(MIN_U32) SWEEP(MAX_I32) SWEEP(BFI) SWEEP(SUB_U32) SWEEP(ASHR) SWEEP(ADD3) SWEEP(AND_OR) SWEEP(MAX3_F32) SWEEP(MIN_F32_LIT) SWEEP(MUL_CLAMP)
+    SWEEP(FMAC) SWEEP(CMP_I32) SWEEP(CMP_CLASS) SWEEP(MOV_DPP) SWEEP(ADD_DPP_ROW) SWEEP(SUB_CO) SWEEP(MED3_I32) SWEEP(LSHL_ADD) SWEEP(MUL_LEGACY) SWEEP(CVT_I32)
     SWEEP(LDS_B128_BCAST) SWEEP(LDS_B64_BCAST) SWEEP(LDS_U16_BCAST) SWEEP(LDS_B128_LANES) SWEEP(LDS_B32_LANES)
     return 0;
 }
