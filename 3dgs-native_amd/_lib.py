@@ -78,6 +78,7 @@ EXPORTS = {
     "gsr_ssim": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp]),
     "gsr_depth_loss": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, vp]),
     "gsr_adam_update": (C.c_int, [C.POINTER(GsrAdam), vp]),
+    "gsr_adam_update_views": (C.c_int, [C.POINTER(GsrAdam), C.c_int32, C.c_int32, C.POINTER(vp), C.c_float, vp]),
     "gsr_sh_grad_from_views": (C.c_int, [C.c_int64, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_float, vp, vp]),
     "gsr_densify_mark": (C.c_int, [C.POINTER(GsrParams), vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp]),
     "gsr_prune_mark": (C.c_int, [C.POINTER(GsrParams), C.c_float, vp, vp]),

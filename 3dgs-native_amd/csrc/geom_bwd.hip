@@ -377,11 +377,7 @@ __global__ __launch_bounds__(256) void view_payload_kernel(int64_t N, const floa
 // One lane per Gaussian: per view it normalises the direction once, forms the 16 basis values with the expressions (and
 // rounding) of the single-view kernel above, and adds basis_k * drgb_c into 48 accumulators; the finished row goes out
 // through the same LDS image as the SH rows everywhere else (12 coalesced 1-KiB stores per wave).
-struct ViewSet {
-    const float *payload[GSR_MAX_VIEWS]; // [N*3] colour-gradient rows, then campos[3]
-};
-
-__global__ __launch_bounds__(256) void sh_grad_from_views_kernel(int64_t N, const float *__restrict__ means, int degree, int V, ViewSet vs,
+__global__ __launch_bounds__(256) void sh_grad_from_views_kernel(int64_t N, const float *__restrict__ means, int degree, int V, ShViewSet vs,
                                                                  float scale, float *__restrict__ dL_dshs)
 {
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
@@ -395,45 +391,7 @@ __global__ __launch_bounds__(256) void sh_grad_from_views_kernel(int64_t N, cons
     for (int k = 0; k < 48; ++k) acc[k] = 0.0f;
     if (i < N) {
         const float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-        for (int v = 0; v < V; ++v) {
-            const float *cp = vs.payload[v] + 3 * N; // wave-uniform: scalar loads
-            const float d[3] = {m[0] - cp[0], m[1] - cp[1], m[2] - cp[2]};
-            const float len = sqrtf(dot3(d, d));
-            const float *gp = vs.payload[v] + 3 * i;
-            const float g[3] = {gp[0], gp[1], gp[2]};
-            if (len < 1e-8f) continue; // backward.py:84-86: no SH gradient for a Gaussian at the camera centre
-            const float x = d[0] / len, y = d[1] / len, z = d[2] / len;
-            float bk[16];
-            const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
-            bk[0] = SH_C0;
-            int nb = 1;
-            if (degree > 0) {
-                bk[1] = -SH_C1 * y; bk[2] = SH_C1 * z; bk[3] = -SH_C1 * x;
-                nb = 4;
-                if (degree > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
-                                C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
-                    bk[4] = C2_0 * xy; bk[5] = C2_1 * yz; bk[6] = C2_2 * (2.0f * zz - xx - yy); bk[7] = C2_3 * xz; bk[8] = C2_4 * (xx - yy);
-                    nb = 9;
-                    if (degree > 2) {
-                        const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
-                                    C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
-                                    C3_6 = -0.5900435899266435f;
-                        bk[9] = C3_0 * y * (3.0f * xx - yy); bk[10] = C3_1 * xy * z; bk[11] = C3_2 * y * (4.0f * zz - xx - yy);
-                        bk[12] = C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); bk[13] = C3_4 * x * (4.0f * zz - xx - yy);
-                        bk[14] = C3_5 * z * (xx - yy); bk[15] = C3_6 * x * (xx - 3.0f * yy);
-                        nb = 16;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < nb) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[3 * k + c] += bk[k] * g[c];
-                }
-        }
+        sh_grad_sum_over_views(vs, V, N, i, m, degree, acc);
     }
     float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
 #pragma unroll
@@ -476,7 +434,7 @@ extern "C" int gsr_sh_grad_from_views(int64_t N, const float *means, int32_t sh_
     if (N == 0) return GSR_OK;
     if (!means || !payloads || !dL_dshs) return GSR_E_NULL;
     if (!gsr_aligned16(dL_dshs)) return GSR_E_ALIGN; // payload rows are read as scalars: rows of a gathered [V][3N+4] block are fine
-    ViewSet vs;
+    ShViewSet vs;
     for (int v = 0; v < GSR_MAX_VIEWS; ++v) {
         vs.payload[v] = v < V ? payloads[v] : nullptr;
         if (v < V && !payloads[v]) return GSR_E_NULL;

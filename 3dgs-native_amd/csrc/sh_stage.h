@@ -180,3 +180,65 @@ __device__ __forceinline__ void sh_direction_sums(const float *sh, int degree, f
     }
 #undef SHV
 }
+
+// ---- SH basis values of a unit direction (the coefficients' multipliers in forward.py:330-344 / backward.py:95-119) ---------
+// bk[0 .. nb) are written, nb = (degree + 1)^2 is returned.  One function for gsr_sh_grad_from_views and the fused
+// Adam-from-views update (train_ops.hip), so both form bit-identical per-view products basis_k * dL_drgb.
+__device__ __forceinline__ int sh_basis(int degree, float x, float y, float z, float bk[16])
+{
+    const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+    bk[0] = SH_C0;
+    int nb = 1;
+    if (degree > 0) {
+        bk[1] = -SH_C1 * y; bk[2] = SH_C1 * z; bk[3] = -SH_C1 * x;
+        nb = 4;
+        if (degree > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                        C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+            bk[4] = C2_0 * xy; bk[5] = C2_1 * yz; bk[6] = C2_2 * (2.0f * zz - xx - yy); bk[7] = C2_3 * xz; bk[8] = C2_4 * (xx - yy);
+            nb = 9;
+            if (degree > 2) {
+                const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                            C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                            C3_6 = -0.5900435899266435f;
+                bk[9] = C3_0 * y * (3.0f * xx - yy); bk[10] = C3_1 * xy * z; bk[11] = C3_2 * y * (4.0f * zz - xx - yy);
+                bk[12] = C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); bk[13] = C3_4 * x * (4.0f * zz - xx - yy);
+                bk[14] = C3_5 * z * (xx - yy); bk[15] = C3_6 * x * (xx - 3.0f * yy);
+                nb = 16;
+            }
+        }
+    }
+    return nb;
+}
+
+// The per-Gaussian sum over views of basis_k(dir_v) * drgb_v[c] (views in order), UNSCALED: acc[3k + c].  `payload[v]` is a
+// view's [N*3 + 4] payload (GsrGrads.dL_drgb): colour-gradient rows, then the camera position.
+struct ShViewSet {
+    const float *payload[GSR_MAX_VIEWS];
+};
+__device__ __forceinline__ void sh_grad_sum_over_views(const ShViewSet &vs, int V, int64_t N, int64_t i, const float m[3], int degree, float acc[48])
+{
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc[k] = 0.0f;
+    for (int v = 0; v < V; ++v) {
+        const float *cp = vs.payload[v] + 3 * N; // wave-uniform: scalar loads
+        const float d[3] = {m[0] - cp[0], m[1] - cp[1], m[2] - cp[2]};
+        float l2 = d[0] * d[0];
+        l2 += d[1] * d[1];
+        l2 += d[2] * d[2];
+        const float len = sqrtf(l2);
+        const float *gp = vs.payload[v] + 3 * i;
+        const float g[3] = {gp[0], gp[1], gp[2]};
+        if (len < 1e-8f) continue; // backward.py:84-86: no SH gradient for a Gaussian at the camera centre
+        const float x = d[0] / len, y = d[1] / len, z = d[2] / len;
+        float bk[16];
+        const int nb = sh_basis(degree, x, y, z, bk);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < nb) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[3 * k + c] += bk[k] * g[c];
+            }
+    }
+}

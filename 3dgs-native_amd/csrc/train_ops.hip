@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "gsr_internal.h"
+#include "sh_stage.h"
 
 namespace {
 
@@ -204,6 +205,62 @@ __global__ __launch_bounds__(256) void adam_sh_kernel(int64_t n4, float4 *__rest
     }
 }
 
+// The same SH update with the gradient formed on the fly from V view payloads (gsr_adam_update_views): lane i builds the 48
+// sums basis_k(dir_v) * drgb_v of ITS Gaussian exactly as gsr_sh_grad_from_views does (sh_stage.h: same function, same order,
+// then the same `* scale`), parks them in the wave's LDS image, and the wave then streams the parameter and moment rows
+// through as whole float4 lines, applying adam_vec3_elem element by element.  The dense gradient (192 bytes per Gaussian
+// written by the backward or the rebuild kernel, then read here) never exists.  Must run BEFORE the position update: the
+// directions are those the forward rendered with.
+__global__ __launch_bounds__(256) void adam_sh_views_kernel(int64_t N, const float *__restrict__ means, int degree, int V, ShViewSet vs,
+                                                            float scale, float4 *__restrict__ p, float4 *__restrict__ m, float4 *__restrict__ v,
+                                                            float lr, AdamK k)
+{
+    __shared__ float4 s_rows[4 * SH_WAVE_F4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
+    const int rows_valid = (int)min((int64_t)64, max((int64_t)0, N - wave_row0));
+    if (rows_valid <= 0) return; // whole wave (no block barrier below)
+    float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
+    const int64_t i = wave_row0 + lane;
+    float acc[48];
+#pragma unroll
+    for (int q = 0; q < 48; ++q) acc[q] = 0.0f;
+    if (i < N) {
+        const float mean[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        sh_grad_sum_over_views(vs, V, N, i, mean, degree, acc);
+    }
+    float *row = reinterpret_cast<float *>(lds_wave + lane * SH_ROW_F4);
+#pragma unroll
+    for (int q = 0; q < 48; ++q) row[q] = acc[q] * scale;
+    wave_lds_fence();
+    // the wave's 64 rows of parameter, first and second moment stream through as whole float4 lines, four at a time per lane
+    // (all twelve at once cost 144 staging registers on top of the 48 sums: one wave per SIMD)
+#pragma unroll 1
+    for (int q0 = 0; q0 < 12; q0 += 4) {
+        float4 pp[4], mm[4], vv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = (q0 + q) * 64 + lane, r = e / 12;
+            const int64_t g = wave_row0 * 12 + (r < rows_valid ? e : 0);
+            pp[q] = p[g]; mm[q] = m[g]; vv[q] = v[g];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = (q0 + q) * 64 + lane, r = e / 12, c = e - r * 12;
+            if (r < rows_valid) {
+                const float4 gg = lds_wave[r * SH_ROW_F4 + c];
+                float4 a = pp[q], b = mm[q], d = vv[q];
+                a.x = adam_vec3_elem(a.x, gg.x, b.x, d.x, lr, k);
+                a.y = adam_vec3_elem(a.y, gg.y, b.y, d.y, lr, k);
+                a.z = adam_vec3_elem(a.z, gg.z, b.z, d.z, lr, k);
+                a.w = adam_vec3_elem(a.w, gg.w, b.w, d.w, lr, k);
+                const int64_t g = wave_row0 * 12 + e;
+                p[g] = a; m[g] = b; v[g] = d;
+            }
+        }
+    }
+}
+
 bool group_ok(const GsrAdamGroup &g) { return g.param && g.grad && g.m && g.v; }
 
 } // namespace
@@ -253,14 +310,22 @@ int gsr_depth_loss(const float *rendered_depth, const float *target_depth, const
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
 }
 
-int gsr_adam_update(const GsrAdam *a, void *stream)
+static int adam_impl(const GsrAdam *a, int32_t sh_degree, int32_t V, const float *const *payloads, float scale, void *stream)
 {
+    const bool views = payloads != nullptr;
     if (!a) return GSR_E_NULL;
     if (a->N < 0) return GSR_E_DIMS;
+    if (views && (V < 1 || V > GSR_MAX_VIEWS || sh_degree < 0 || sh_degree > 3 || a->N > ((int64_t)1 << 27))) return GSR_E_DIMS;
     if (a->N == 0) return GSR_OK;
-    if (!group_ok(a->pos) || !group_ok(a->scale) || !group_ok(a->rot) || !group_ok(a->opacity) || !group_ok(a->sh)) return GSR_E_NULL;
+    if (!group_ok(a->pos) || !group_ok(a->scale) || !group_ok(a->rot) || !group_ok(a->opacity)) return GSR_E_NULL;
+    if (!a->sh.param || !a->sh.m || !a->sh.v || (!views && !a->sh.grad)) return GSR_E_NULL;
     for (const GsrAdamGroup *g : {&a->pos, &a->scale, &a->rot, &a->opacity, &a->sh})
         if (!gsr_aligned16(g->param) || !gsr_aligned16(g->grad) || !gsr_aligned16(g->m) || !gsr_aligned16(g->v)) return GSR_E_ALIGN;
+    ShViewSet vs;
+    for (int q = 0; q < GSR_MAX_VIEWS; ++q) {
+        vs.payload[q] = (views && q < V) ? payloads[q] : nullptr;
+        if (views && q < V && !payloads[q]) return GSR_E_NULL;
+    }
     hipStream_t s = (hipStream_t)stream;
     AdamK k;
     k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = a->epsilon;
@@ -268,14 +333,27 @@ int gsr_adam_update(const GsrAdam *a, void *stream)
     // bias corrections in float32 on the host: 1 - pow(beta, float(iteration + 1))   (optimizer.py:47-48)
     k.bc1 = 1.0f - powf(a->beta1, (float)(a->iteration + 1));
     k.bc2 = 1.0f - powf(a->beta2, (float)(a->iteration + 1));
+    if (views) // first: it needs the positions the views were rendered with
+        hipLaunchKernelGGL(adam_sh_views_kernel, dim3((unsigned)gsr_div_up(a->N, 256)), dim3(256), 0, s, a->N, a->pos.param, (int)sh_degree, (int)V, vs,
+                           scale, (float4 *)a->sh.param, (float4 *)a->sh.m, (float4 *)a->sh.v, a->sh.lr, k);
     hipLaunchKernelGGL(adam_small_kernel, dim3((unsigned)gsr_div_up(a->N, 256)), dim3(256), 0, s, a->N, a->pos.param, a->pos.grad, a->pos.m,
                        a->pos.v, a->pos.lr, a->scale.param, a->scale.grad, a->scale.m, a->scale.v, a->scale.lr, a->rot.param, a->rot.grad,
                        a->rot.m, a->rot.v, a->rot.lr, a->opacity.param, a->opacity.grad, a->opacity.m, a->opacity.v, a->opacity.lr, k);
-    const int64_t n4 = a->N * 12; // 48 floats per Gaussian
-    const unsigned blocks = (unsigned)std::min<int64_t>(4096, gsr_div_up(n4, 256));
-    hipLaunchKernelGGL(adam_sh_kernel, dim3(blocks), dim3(256), 0, s, n4, (float4 *)a->sh.param, (const float4 *)a->sh.grad, (float4 *)a->sh.m,
-                       (float4 *)a->sh.v, a->sh.lr, k);
+    if (!views) {
+        const int64_t n4 = a->N * 12; // 48 floats per Gaussian
+        const unsigned blocks = (unsigned)std::min<int64_t>(4096, gsr_div_up(n4, 256));
+        hipLaunchKernelGGL(adam_sh_kernel, dim3(blocks), dim3(256), 0, s, n4, (float4 *)a->sh.param, (const float4 *)a->sh.grad, (float4 *)a->sh.m,
+                           (float4 *)a->sh.v, a->sh.lr, k);
+    }
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
+}
+
+int gsr_adam_update(const GsrAdam *a, void *stream) { return adam_impl(a, 0, 0, nullptr, 1.0f, stream); }
+
+int gsr_adam_update_views(const GsrAdam *a, int32_t sh_degree, int32_t V, const float *const *payloads, float scale, void *stream)
+{
+    if (!payloads) return GSR_E_NULL;
+    return adam_impl(a, sh_degree, V, payloads, scale, stream);
 }
 
 } // extern "C"

@@ -50,6 +50,12 @@ CONFIGS = {
     "C2": dict(n=100_000, scale_median=0.02, scale_sigma=0.5, seed=1234, width=800, height=800),
     "C3": dict(n=1_000_000, scale_median=0.01, scale_sigma=0.6, seed=2025, width=800, height=800),
     "C5": dict(n=5_000_000, scale_median=0.005, scale_sigma=0.6, seed=5, width=1920, height=1080),
+    # The regime the reference trainer STARTS in (train.py:37-92, config.py:30-31,62): its own initial point set -- positions
+    # randf-hashed in (-1.3, 1.3)^3, constant scale 0.1, opacity 0.1, quaternion (1,0,0,0) as stored -- at the reference's
+    # default 5 000 points (C0) and at 100 000 (C2i; SURVEY.md section 6 "#2-like, reference init": D = 12.1 M, 4 854 entries
+    # per tile).  Built on the device by gsr_init_gaussians (densify.init_gaussian_params), not by synthetic_scene.
+    "C0": dict(n=5_000, init_scale=0.1, width=800, height=800, seed=0),
+    "C2i": dict(n=100_000, init_scale=0.1, width=800, height=800, seed=0),
 }
 
 # Lego train frame 0 (reference data/lego/transforms_train.json), used as the benchmark pose so

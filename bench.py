@@ -141,7 +141,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5", "C0", "C2i"], help="C3 is the headline workload; C0 / C2i are the "
+                    "reference trainer's initial point set (5 000 / 100 000 Gaussians of scale 0.1), not headline configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend; nccl is RCCL (default). gloo + "
@@ -187,7 +188,12 @@ def main():
     gsr = importlib.import_module("3dgs-native_amd")
     cfg = gsr.scenes.CONFIGS[args.config]
     W, H, N = cfg["width"], cfg["height"], cfg["n"]
-    sc = gsr.scenes.synthetic_scene(N, cfg["scale_median"], cfg["scale_sigma"], cfg["seed"])  # same on every rank
+    if "init_scale" in cfg:     # the reference trainer's initial point set, built on the device (same on every rank)
+        ip = gsr.densify.init_gaussian_params(N, cfg["init_scale"], dev)
+        sc = {"means": ip["positions"].cpu().numpy(), "shs": ip["shs"].cpu().numpy().reshape(N, 16, 3), "opacities": ip["opacities"].cpu().numpy().reshape(N, 1),
+              "scales": ip["scales"].cpu().numpy(), "rotations": ip["rotations"].cpu().numpy()}
+    else:
+        sc = gsr.scenes.synthetic_scene(N, cfg["scale_median"], cfg["scale_sigma"], cfg["seed"])  # same on every rank
     pose = gsr.scenes.LEGO_FRAME0 if world == 1 else gsr.scenes.orbit_pose(rank, world)
     cam = gsr.cameras.nerf_camera(pose, W, H, gsr.scenes.LEGO_CAMERA_ANGLE_X)
     bg = np.zeros(3, np.float32)
@@ -288,7 +294,7 @@ def main():
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: synthetic {W}x{H}, {N} Gaussians, SH degree 3, seed {cfg['seed']}, forward+backward, "
+        "config": {"workload": f"{args.config}: {'reference initial point set (scale ' + str(cfg['init_scale']) + ')' if 'init_scale' in cfg else 'synthetic'} {W}x{H}, {N} Gaussians, SH degree 3, seed {cfg['seed']}, forward+backward, "
                                f"Lego train pose 0" + (" rotated per rank" if world > 1 else ""),
                    "width": W, "height": H, "gaussians": N, "visible": Nv, "tile_pairs_D": D, "views_per_step": world * vps,
                    "parallelism": f"dp{world}: {'one view' if vps == 1 else str(vps) + ' views on ' + str(vps) + ' streams'} per GPU, replicated Gaussians" + ((f", {backend_name} all-reduce of the 59-float gradient arena" if args.dense_exchange else

@@ -79,6 +79,8 @@ def main():
                     "init_gaussian_params, or a seeded random scene")
     ap.add_argument("--backend", default=None, help="collective backend (default: nccl = RCCL); gloo + --single-device rehearses N ranks on one GPU")
     ap.add_argument("--single-device", action="store_true")
+    ap.add_argument("--dense-sh", action="store_true", help="materialise the 48-float SH gradient (backward's dense return, one "
+                    "59-float all-reduce when N > 1) instead of forming it inside the Adam update from the view payloads")
     ap.add_argument("--output", default=None, help="directory for point_cloud/iteration_N/point_cloud.ply")
     args = ap.parse_args()
 
@@ -131,7 +133,10 @@ def main():
         batch = rng.choice(len(cams), size=args.views_per_step, replace=False)
         mine = [int(batch[i]) for i in gsr.dist.views_for_rank(len(batch), rank, world)]
         arena, loss_acc, payloads = None, torch.zeros(1, device=dev), []
-        factored = world > 1      # N > 1: exchange 11 + 3 floats per Gaussian instead of 59 (dist.py)
+        # The SH gradient is never materialised: backward() returns the 3-float view payload it is an outer product of, the
+        # ranks exchange that (11 + 3 floats per Gaussian instead of 59, dist.py) and the Adam kernel forms basis x payload
+        # inside the SH update (optimizer.adam_update(sh_views=...)) -- also with one rank.  --dense-sh keeps the 48-float path.
+        factored = not args.dense_sh
         for v in mine:
             c = cams[v]
             kw = dict(background=bg, means3D=P["positions"], opacity=P["opacities"], scales=P["scales"], rotations=P["rotations"],
@@ -159,16 +164,20 @@ def main():
             arena.mul_(world / len(batch))                                  # mean over the batch after the /world of the average
             gathered = gsr.dist.exchange_factored(arena, torch.stack(payloads).view(-1), average=True)
             grads = gsr.dist.small_arena_views(arena, n)
-            grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(P["positions"], gathered.view(world * per_rank, 3 * n + 4), 3,
-                                                                scale=1.0 / len(batch))
+            grads["dL_dshs"] = None
+            sh_views, sh_scale = gathered.view(world * per_rank, 3 * n + 4), 1.0 / len(batch)
+            if sh_views.shape[0] > gsr.dist.MAX_VIEWS_PER_CALL:             # more views than one kernel call takes: rebuild in chunks
+                grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(P["positions"], sh_views, 3, scale=sh_scale)
+                sh_views, sh_scale = None, None
         else:
             if arena is None:
                 arena = torch.zeros(gsr.dist.arena_size(n), device=dev)
             arena.mul_(1.0 / max(1, len(batch)))
             grads = gsr.dist.arena_views(arena, n)
+            sh_views, sh_scale = None, None
         lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}
         model.grads = gsr.optimizer.grads_from_backward(grads)              # train.py:1047-1051
-        gsr.optimizer.adam_update(P, model.grads, M, V, lrs, iteration=it)
+        gsr.optimizer.adam_update(P, model.grads, M, V, lrs, iteration=it, sh_views=sh_views, sh_degree=3, sh_scale=sh_scale)
         log = model.densification_and_pruning(it)                           # train.py:1060
         if rank == 0 and (log["cloned"] or log["split"] or log["pruned"] or log["opacity_reset"]):
             print(f"iter {it:5d}  densify: +{log['cloned']} cloned, {log['split']} split, -{log['pruned']} pruned"

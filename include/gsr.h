@@ -245,6 +245,13 @@ int gsr_adam_update(const GsrAdam *adam, void *stream);
 #define GSR_MAX_VIEWS 16
 int gsr_sh_grad_from_views(int64_t N, const float *means, int32_t sh_degree, int32_t V, const float *const *payloads, float scale,
                            float *dL_dshs /* [N*16*3] out */, void *stream);
+/* gsr_adam_update with the SH gradient formed on the fly: adam->sh.grad is ignored (may be NULL) and the SH group is updated
+ * with scale * sum_v basis_k(dir_v) * drgb_v -- bit for bit what gsr_sh_grad_from_views(adam->N, adam->pos.param, ...) followed
+ * by gsr_adam_update would apply (the same products in the same order), without the 192-byte-per-Gaussian gradient ever being
+ * written or read.  The directions use adam->pos.param BEFORE this call updates it (the positions the views were rendered
+ * with).  V = 1 with the payload of backward(..., sh_gradient="factored") is the single-GPU trainer's step
+ * (reference optimizer.py:128-139 + backward.py:95-255). */
+int gsr_adam_update_views(const GsrAdam *adam, int32_t sh_degree, int32_t V, const float *const *payloads, float scale, void *stream);
 
 /* ---- row f4: adaptive density control --------------------------------
  * Replaces the Warp kernels the reference trainer launches in densification_and_pruning()

@@ -240,6 +240,8 @@ int gsr_adam_update(const GsrAdam *a, void *stream)
 /* ---- symbols whose oracle is numpy (oracle/densify.py) or that are product-only: present, not implemented ---- */
 int gsr_sh_grad_from_views(int64_t N, const float *means, int32_t deg, int32_t V, const float *const *p, float s, float *o, void *st)
 { (void)N; (void)means; (void)deg; (void)V; (void)p; (void)s; (void)o; (void)st; return GSR_E_HIP; }
+int gsr_adam_update_views(const GsrAdam *a, int32_t deg, int32_t V, const float *const *p, float s, void *st)
+{ (void)a; (void)deg; (void)V; (void)p; (void)s; (void)st; return GSR_E_HIP; }
 int gsr_densify_mark(const GsrParams *p, const float *g, int64_t n, float a, float b, float c, int m, int32_t *mask, void *s)
 { (void)p; (void)g; (void)n; (void)a; (void)b; (void)c; (void)m; (void)mask; (void)s; return GSR_E_HIP; }
 int gsr_prune_mark(const GsrParams *p, float t, int32_t *v, void *s) { (void)p; (void)t; (void)v; (void)s; return GSR_E_HIP; }

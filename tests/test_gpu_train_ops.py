@@ -52,6 +52,44 @@ def test_adam_update_matches_oracle(oracle):
     np.testing.assert_allclose(dP["rotations"].norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("V,degree,n", [(1, 3, 3001), (3, 3, 1000), (8, 2, 517), (2, 0, 64), (16, 1, 130)])
+def test_adam_from_view_payloads_is_the_same_step(V, degree, n):
+    """gsr_adam_update_views: the SH group updated from V view payloads inside the kernel must leave, bit for
+    bit, the parameters and moments that dist.sh_gradients_from_views + adam_update leave -- same per-view products, same
+    order, same scale, same element update -- over several steps, for every degree, with ragged N and a Gaussian at a camera."""
+    import torch
+    gsr = pkg()
+    rng = np.random.default_rng(100 * V + degree)
+    shapes = {"positions": (n, 3), "scales": (n, 3), "rotations": (n, 4), "opacities": (n,), "shs": (n * 16, 3)}
+    P0 = {k: rng.normal(0, 1, s).astype(np.float32) for k, s in shapes.items()}
+    P0["scales"] = np.abs(P0["scales"]) * 0.01
+    P0["opacities"] = rng.uniform(0, 1, n).astype(np.float32)
+    cams = rng.normal(0, 3, (V, 3)).astype(np.float32)
+    P0["positions"][0] = cams[0]                                   # direction of length 0: no SH gradient from that view
+    mk = lambda d: {k: torch.as_tensor(v.copy()).cuda() for k, v in d.items()}
+    zeros = lambda: {k: torch.zeros(s, dtype=torch.float32).cuda() for k, s in shapes.items()}
+    Pa, Ma, Va = mk(P0), zeros(), zeros()
+    Pb, Mb, Vb = mk(P0), zeros(), zeros()
+    lrs = gsr.optimizer.DEFAULT_LR
+    for it in range(3):
+        pay = torch.zeros((V, 3 * n + 4), dtype=torch.float32)
+        pay[:, :3 * n] = torch.as_tensor((rng.normal(0, 1e-3, (V, 3 * n)) * (rng.uniform(0, 1, (V, 3 * n)) > 0.2)).astype(np.float32))
+        pay[:, 3 * n:3 * n + 3] = torch.as_tensor(cams)
+        pay = pay.cuda()
+        G = {k: torch.as_tensor(rng.normal(0, 1e-3, s).astype(np.float32)).cuda() for k, s in shapes.items() if k != "shs"}
+        # (a) rebuild the dense SH gradient, then the plain update
+        Ga = dict(G, shs=gsr.dist.sh_gradients_from_views(Pa["positions"], pay, degree, average=True))
+        gsr.optimizer.adam_update(Pa, Ga, Ma, Va, lrs, iteration=it)
+        # (b) the fused update, no dense gradient anywhere
+        gsr.optimizer.adam_update(Pb, dict(G, shs=None), Mb, Vb, lrs, iteration=it, sh_views=pay, sh_degree=degree)
+        for k in shapes:
+            assert torch.equal(Pa[k], Pb[k]), f"param {k} it {it}"
+            assert torch.equal(Ma[k], Mb[k]) and torch.equal(Va[k], Vb[k]), f"moments {k} it {it}"
+    assert float((Pb["shs"] - torch.as_tensor(P0["shs"]).cuda()).abs().max()) > 0.0
+    with pytest.raises(ValueError):
+        gsr.optimizer.adam_update(Pb, dict(G, shs=None), Mb, Vb, lrs, iteration=0, sh_views=pay[:, :-1].contiguous())
+
+
 def test_training_iterations_reduce_the_loss(cameras, scenes):
     """forward -> L1 loss/grad -> backward -> Adam, 25 iterations on a small scene against a fixed target."""
     import torch
