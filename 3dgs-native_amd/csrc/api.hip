@@ -260,6 +260,8 @@ void read_tuning()
     std::call_once(g_tuning_once, [] {
         if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e) & GSR_DEBUG_ALLOWED;
         if (const char *e = getenv("GSR_BWD_BLOCK")) gsr_bwd_block = atoi(e);
+        if (const char *e = getenv("GSR_BWD_XCD")) gsr_bwd_xcd_map = atoi(e) != 0;
+        if (const char *e = getenv("GSR_FWD_XCD")) gsr_fwd_xcd_map = atoi(e) != 0;
     });
 }
 
@@ -273,6 +275,9 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.rect = c.take<TileRect>((size_t)N);
     w.depth_item = c.take<uint64_t>((size_t)N);
     w.sort_tmp = c.take<uint64_t>((size_t)N);
+    w.id_sorted = c.take<uint32_t>((size_t)N);
+    w.blk_minmax = c.take<uint32_t>(2 * (size_t)gsr_div_up(N, 256) + 4);
+    w.depth_ctl = c.take<uint32_t>(4);
     w.rect_sorted = c.take<TileRect>((size_t)N);
     w.cnt_sorted = c.take<int32_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);
@@ -340,21 +345,15 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     if (!rb) return GSR_E_HIP;
     // the scan's last wave stores D = point_offsets[N-1] straight into the pinned host word
     // (preprocess left one partial sum per 256 Gaussians in scan_tmp: one launch)
-    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s));
+    // (its first wave also turns the per-block depth extremes preprocess left into the depth sort's pass plan, on the device)
+    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s, ws.blk_minmax, ws.depth_ctl));
     mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
     // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id order, four 8-bit
     // passes over the high word, ending back in depth_item; the last one also carries each Gaussian's tile rectangle and
     // tile count to its sorted position) and the depth-order offsets (exclusive scan of those counts).
     {
-        uint64_t *src = ws.depth_item, *dst = ws.sort_tmp;
-        for (int pass = 0; pass < 3; ++pass) {
-            // pass p accumulates into acc[p & 1] (cleared by preprocess for p = 0) and clears the other one for pass p + 1
-            HIP_TRY(gsr_launch_radix_pass(src, dst, ws.hist, ws.acc[pass & 1], N, 32 + 8 * pass, 8, 8, ws.acc[(pass + 1) & 1], s));
-            uint64_t *t = src; src = dst; dst = t;
-        }
-        // the last pass also carries each Gaussian's tile rectangle and tile count to its sorted position
-        HIP_TRY(gsr_launch_depth_last_pass(src, dst, ws.hist, ws.acc[1], N, 56, ws.rect, ws.rect_sorted, ws.cnt_sorted, s));
+        HIP_TRY(gsr_launch_depth_sort(ws, N, s));
         mark(st, 3, s);
         HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
         mark(st, 4, s);
@@ -412,7 +411,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     while ((1LL << id_bits) < N) ++id_bits;
     const bool narrow = tb + id_bits <= 32 && !(gsr_debug_flags & 32); // GSR_DEBUG bit 5: 64-bit tile items at any size (tests)
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
-    HIP_TRY(gsr_launch_expand(gw.depth_item, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
+    HIP_TRY(gsr_launch_expand(gw.id_sorted, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
                               (int)gsr_radix_acc_ints(D), s));
     mark(st, 6, s);
     // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible

@@ -35,7 +35,7 @@ __device__ unsigned long long g_bwd_wave[TLB_MAX_WAVES][12];
 #define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, (unsigned long long)tl_t, 0, 0};
 #define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
 #define TL_COUNT(k, v) tl_acc[k] += (v);
-#define TL_FLUSH if (threadIdx.x == 0) { const int tw = blockIdx.x & (TLB_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_bwd_wave[tw][q] = tl_acc[q]; \
+#define TL_FLUSH if (threadIdx.x == 0) { const int tw = bid & (TLB_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_bwd_wave[tw][q] = tl_acc[q]; \
         g_bwd_wave[tw][8] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
         g_bwd_wave[tw][9] = tl_r0; g_bwd_wave[tw][10] = __builtin_amdgcn_s_memrealtime(); }
 #elif defined(GSR_CENSUS)
@@ -46,7 +46,7 @@ __device__ unsigned long long g_bwd_census[1 << 17][4];
 #define TL_DECL const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
 #define TL(k)
 #define TL_COUNT(k, v)
-#define TL_FLUSH if (threadIdx.x == 0) { unsigned long long *cw = g_bwd_census[blockIdx.x & ((1 << 17) - 1)]; \
+#define TL_FLUSH if (threadIdx.x == 0) { unsigned long long *cw = g_bwd_census[bid & ((1 << 17) - 1)]; \
         cw[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
         cw[1] = tl_r0; cw[2] = __builtin_amdgcn_s_memrealtime(); }
 #else
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                                                                   const float *__restrict__ final_T,
                                                                   const int32_t *__restrict__ n_contrib,
                                                                   const float *__restrict__ dL_dpixels,
-                                                                  const uint8_t *__restrict__ block_masks, GradRec *__restrict__ acc, int dbg)
+                                                                  const uint8_t *__restrict__ block_masks, GradRec *__restrict__ acc, int dbg, int xcd_map, int n_blocks)
 {
     constexpr int NPIX = BW * BH;            // pixels of the block this wave owns
     constexpr int PER_TILE = 256 / NPIX;     // blocks per 16x16 tile
@@ -203,7 +203,16 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     __shared__ int s_id[64];
 
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x / PER_TILE, sub = blockIdx.x % PER_TILE;
+    // Workgroup ids are handed to the eight XCDs round-robin, so consecutive ids -- the PER_TILE blocks of one tile, which read
+    // the same list, masks and records -- land on eight different L2s.  xcd_map != 0: XCD x takes the x-th eighth of the blocks
+    // instead, so that a tile's blocks run on ONE XCD, next to each other in its queue (grid = 8 * ceil(blocks / 8)).
+    int bid = blockIdx.x;
+    if (xcd_map) {
+        const int per = gridDim.x >> 3;
+        bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (bid >= n_blocks) return;
+    }
+    const int tile = bid / PER_TILE, sub = bid % PER_TILE;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
     const int start = range.x, end = range.y;
@@ -462,6 +471,7 @@ extern "C" int gsr_debug_bwd_phases(unsigned long long *out /* [waves][12] */, i
 #endif
 
 int gsr_bwd_block = 32;
+int gsr_bwd_xcd_map = 1;   // GSR_BWD_XCD (see the kernel): on by default, 171 -> 165 us at C3
 int gsr_debug_flags = 0; // see gsr_internal.h
 
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
@@ -471,9 +481,13 @@ hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *range
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
 #define LAUNCH(BW, BH, M)                                                                                                     \
-    hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH, M>), dim3(tiles * (256 / ((BW) * (BH)))), dim3(64), 0, s, cam.W, cam.H, \
-                       cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib,      \
-                       dL_dpixels, block_masks, acc, gsr_debug_flags)
+    do {                                                                                                                      \
+        const int nblk = tiles * (256 / ((BW) * (BH)));                                                                       \
+        const int grid = gsr_bwd_xcd_map ? 8 * ((nblk + 7) / 8) : nblk;                                                       \
+        hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH, M>), dim3(grid), dim3(64), 0, s, cam.W, cam.H, cam.grid_x,    \
+                           cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels,  \
+                           block_masks, acc, gsr_debug_flags, gsr_bwd_xcd_map, nblk);                                         \
+    } while (0)
     switch (gsr_bwd_block) { // pixels per wave: GSR_BWD_BLOCK = 32 (8x4, default: measured best at C3), 64 (8x8), 16 (4x4)
     case 16: LAUNCH(4, 4, false); break;
     case 64: if (block_masks) LAUNCH(8, 8, true); else LAUNCH(8, 8, false); break;

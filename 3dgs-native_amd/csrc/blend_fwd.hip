@@ -33,7 +33,7 @@ __device__ unsigned long long g_fwd_wave[TL_MAX_WAVES][8]; // one row per wave, 
 #define TL_DECL long long tl_t = __builtin_amdgcn_s_memtime(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TL(k) { const long long tl_n = __builtin_amdgcn_s_memtime(); tl_acc[k] += (unsigned long long)(tl_n - tl_t); tl_t = tl_n; }
 #define TL_COUNT(k, v) tl_acc[k] += (v);
-#define TL_FLUSH if (lane == 0) { const int tw = (blockIdx.x * 4 + wv) & (TL_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_fwd_wave[tw][q] = tl_acc[q]; }
+#define TL_FLUSH if (lane == 0) { const int tw = (tile * 4 + wv) & (TL_MAX_WAVES - 1); for (int q = 0; q < 8; ++q) g_fwd_wave[tw][q] = tl_acc[q]; }
 #elif defined(GSR_CENSUS)
 // GSR_CENSUS (diagnostic build, `make census`): the product kernel plus three scalar stamps per wave (HW_ID | XCC_ID,
 // s_memrealtime start / end) for tools/residency.py
@@ -41,7 +41,7 @@ __device__ unsigned long long g_fwd_census[1 << 17][4];
 #define TL_DECL const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
 #define TL(k)
 #define TL_COUNT(k, v)
-#define TL_FLUSH if (lane == 0) { unsigned long long *cw = g_fwd_census[(blockIdx.x * 4 + wv) & ((1 << 17) - 1)]; \
+#define TL_FLUSH if (lane == 0) { unsigned long long *cw = g_fwd_census[(tile * 4 + wv) & ((1 << 17) - 1)]; \
         cw[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
         cw[1] = tl_r0; cw[2] = __builtin_amdgcn_s_memrealtime(); }
 #else
@@ -104,14 +104,21 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
                                                             const int32_t *__restrict__ point_list,
                                                             const BlendRec *__restrict__ rec, float *__restrict__ image,
                                                             float *__restrict__ inv_depth, float *__restrict__ final_T,
-                                                            int32_t *__restrict__ n_contrib, uint8_t *__restrict__ block_masks)
+                                                            int32_t *__restrict__ n_contrib, uint8_t *__restrict__ block_masks, int xcd_map,
+                                                            int n_tiles)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(BATCH + 1) * REC_BYTES]; // + one sentinel record (opacity 0: never valid)
     __shared__ uint8_t s_mask[BATCH];                      // bit k: entry may touch 8x4 block k (k & 1 = x half, k >> 1 = row band)
     __shared__ uint16_t s_list[NWAVES][BATCH + LIST_PAD];  // per wave: byte offsets (into s_rec) of its live entries, in list order
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x;
+    // xcd_map: workgroup ids go to the eight XCDs round-robin; with the map XCD x renders the x-th eighth of the tiles (a band
+    // of rows), so neighbouring tiles -- which share most of their Gaussians -- share an L2 (grid = 8 * ceil(tiles / 8))
+    int tile = blockIdx.x;
+    if (xcd_map) {
+        tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if (tile >= n_tiles) return;
+    }
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int pix_x = tile_x * 16 + (wv & 1) * 8 + (lane & 7);
     const int pix_y = tile_y * 16 + (wv >> 1) * 8 + (lane >> 3);
@@ -314,12 +321,15 @@ extern "C" int gsr_debug_fwd_phases(unsigned long long *out /* [waves][8] */, in
 }
 #endif
 
+int gsr_fwd_xcd_map = 0; // GSR_FWD_XCD (see the kernel)
+
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
                                     const GsrImage &img, uint8_t *block_masks, hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
-                       ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks);
+    const int grid = gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles;
+    hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
+                       ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks, gsr_fwd_xcd_map, tiles);
     return hipGetLastError();
 }

@@ -37,8 +37,11 @@ static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 struct GeomWs {
     BlendRec *rec;        // [N]
     TileRect *rect;       // [N]
-    uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled; sorted by depth after gsr_forward_count
+    uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled: the depth sort's input
     uint64_t *sort_tmp;   // [N] ping-pong partner of depth_item
+    uint32_t *id_sorted;  // [N] Gaussian ids in depth order (written by the last depth-sort pass)
+    uint32_t *blk_minmax; // [2 * ceil(N / 256)] smallest / largest visible depth bits per preprocess block
+    void *depth_ctl;      // DepthCtl (scan_sort.hip): this frame's depth range and pass count, decided on the device
     TileRect *rect_sorted; // [N] tile rectangles in depth order (written by the last depth-sort pass)
     int32_t *cnt_sorted;  // [N] tile counts in depth order (same pass)
     int32_t *doff;        // [N] exclusive tile-pair offsets in depth order
@@ -57,7 +60,9 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
                            int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */,
-                           bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s);
+                           bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s,
+                           const uint32_t *blk_minmax = nullptr, void *depth_ctl = nullptr /* mode 0: also derive the depth sort's DepthCtl */);
+hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s);
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096
@@ -88,9 +93,7 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
                                        int id_shift, int32_t *point_list, int32_t *ranges /* pre-zeroed */, int32_t *edge, hipStream_t s);
 
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
-hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *acc, int64_t n, int shift,
-                                      const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s);
-hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items,
+hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
                              int32_t *zero_acc, int zero_n /* accumulators of the first partition pass, cleared here */, hipStream_t s);
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
@@ -110,16 +113,19 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 // tuning knobs (read once from the environment by api.hip; defaults are the measured best)
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
 // GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks, bit 7 the scanned
-// super-block rows of many-block radix passes (radix_superscan_kernel) -- same results by
+// super-block rows of many-block radix passes (radix_superscan_kernel), bit 8 all four depth-sort passes whatever the depth
+// range -- same results by
 // other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
 // one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->
 // libgsr_hip_ablate.so, -DGSR_ABLATE, used by tools/stage_bench.sh) and are compiled out of libgsr_hip.so.
 #ifdef GSR_ABLATE
-#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128)
+#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128 | 256)
 #define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
 #else
-#define GSR_DEBUG_ALLOWED (32 | 64 | 128)
+#define GSR_DEBUG_ALLOWED (32 | 64 | 128 | 256)
 #define GSR_ABL(flags, bit) false
 #endif
 extern int gsr_debug_flags;
+extern int gsr_fwd_xcd_map;        // GSR_FWD_XCD: neighbouring tiles of the forward blend on one XCD (blend_fwd.hip)
+extern int gsr_bwd_xcd_map;        // GSR_BWD_XCD: a tile's blocks of the backward blend on one XCD (blend_bwd_splat.hip)
 extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)

@@ -65,9 +65,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
     uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ block_tile_sums,
-    float *__restrict__ sh_dir_grad, int dbg)
+    float *__restrict__ sh_dir_grad, uint32_t *__restrict__ blk_minmax, int dbg)
 {
     __shared__ int s_tiles[4];
+    __shared__ uint32_t s_dmin[4], s_dmax[4];
     // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
     // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
@@ -187,6 +188,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
         t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
         if (lane == 63) s_tiles[wv] = t;
+        // the block's smallest and largest VISIBLE depth bits, for the depth sort's pass plan (scan_sort.hip, DepthCtl)
+        uint32_t lo = (visible && in_range) ? __float_as_uint(o_depth) : 0xFFFFFFFFu, hi = (visible && in_range) ? __float_as_uint(o_depth) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+        }
+        if (lane == 0) { s_dmin[wv] = lo; s_dmax[wv] = hi; }
     }
     sh_rows_commit(sh_regs, lds_wave, lane);
     // in_range: tail lanes redo the last Gaussian; their rows do not exist (found by tests/test_gpu_fuzz.py: N = 1, one big
@@ -197,7 +206,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         sh_rows_commit_masked(sh_regs, lds_wave, lane, late_mask);
     }
     __syncthreads(); // SH rows have landed in LDS
-    if (threadIdx.x == 0) block_tile_sums[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
+    if (threadIdx.x == 0) {
+        block_tile_sums[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
+        reinterpret_cast<uint2 *>(blk_minmax)[blockIdx.x] = make_uint2(min(min(s_dmin[0], s_dmin[1]), min(s_dmin[2], s_dmin[3])),
+                                                                       max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3])));
+    }
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian
                 const float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
@@ -291,6 +304,6 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
                        g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, ws.acc[0],
-                       (int)gsr_radix_acc_ints(sc.N), ws.scan_tmp, g.sh_dir_grad, gsr_debug_flags);
+                       (int)gsr_radix_acc_ints(sc.N), ws.scan_tmp, g.sh_dir_grad, ws.blk_minmax, gsr_debug_flags);
     return hipGetLastError();
 }

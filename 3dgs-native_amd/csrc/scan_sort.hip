@@ -87,13 +87,75 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 
 // SUMS_PER_UNIT: `wave_sums` holds that many partial sums per 1024-item unit (1 from scan_reduce_kernel; 4 when the kernel that
 // produced `in` wrote one sum per 256 items itself -- preprocess does, which saves the reduce launch of the id-order scan).
+// What the depth sort needs to know about this frame's depths (device memory: the host never sees it).  The visible depth bits
+// lie in [min_bits, min_bits + range - 1]; the sort key of a Gaussian is umin(bits - min_bits, range) -- the same order as the
+// bits themselves (positive floats order like their bit patterns), culled Gaussians (bits 0xFFFFFFFF) all at `range`, behind
+// every visible one, in id order -- and only the low `8 * npass` bits of it can differ.  A typical scene spans less than two
+// octaves of depth around the camera distance: range < 2^24, three 8-bit passes instead of four.
+struct DepthCtl {
+    uint32_t min_bits, range;
+    int32_t npass, first; // passes 0 .. 3 are launched; pass p sorts digit p - first, passes below `first` = 4 - npass exit at once
+};
+
+// Run by ONE wave of the id-order scan (which follows preprocess in the stream and precedes the depth passes): preprocess left
+// the smallest and largest visible depth bits of every 256-Gaussian block (0xFFFFFFFF / 0 for a block without a visible one).
+__device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass)
+{
+    // one 256-thread workgroup; 16-byte loads (two blocks each), all of a thread's loads in flight before anything is combined:
+    // 8 bytes x N / 256 (31 KB at a million Gaussians) in one or two memory round trips
+    __shared__ uint32_t s_lo[4], s_hi[4];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    const int npair = nblk >> 1;
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(blk_minmax);
+    for (int b0 = 0; b0 < npair; b0 += 256 * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * 256 + (int)threadIdx.x;
+            v[k] = b < npair ? p4[b] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            lo = min(lo, min(v[k].x, v[k].z));
+            hi = max(hi, max(v[k].y, v[k].w));
+        }
+    }
+    if ((nblk & 1) && threadIdx.x == 0) {
+        lo = min(lo, blk_minmax[2 * (nblk - 1)]);
+        hi = max(hi, blk_minmax[2 * (nblk - 1) + 1]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        DepthCtl c;
+        if (lo > hi) { c.min_bits = 0xFFFFFFFFu; c.range = 0u; } // nothing visible: every key is 0, one pass (it carries the rectangles)
+        else { c.min_bits = lo; c.range = hi - lo + 1u; }
+        const int nbits = 32 - __builtin_clz(c.range | 1u);      // keys are 0 .. range
+        c.npass = force_npass > 0 ? force_npass : max(1, (nbits + 7) / 8); // forced (tests: GSR_DEBUG bit 8 = always four): same order
+        c.first = 4 - c.npass;
+        *ctl = c;
+    }
+}
+
 template <int MODE, int SUMS_PER_UNIT>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
-                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out)
+                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out,
+                                                         const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t base = wid * SCAN_WAVE_ITEMS;
+    if (ctl && blockIdx.x == gridDim.x - 1) { // one extra workgroup, launched for this alone: off the scan's critical path
+        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass);
+        return;
+    }
     if (base >= n) return;
     // all 16 rounds are loaded before anything else: left to itself the compiler emits load -> wait -> scan -> store per
     // round (the stores' branches fence the loads), a chain of 16 memory round trips per wave
@@ -152,12 +214,36 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 // hist) -- about 2 sqrt(nb) coalesced 16-byte loads spread over the block instead of a launch.  acc[0..255] receives the
 // totals from block 0 of a FINAL scatter (ranges_fixup_kernel reads them).  The accumulators of a pass are zeroed by the kernel that precedes its
 // histogram kernel in the stream (preprocess / expand for the first pass, the previous pass's scatter after that).
-template <int RADIX_ITEMS, int BITS, typename ItemT>
+// DEPTH (the four depth passes over the 64-bit depth|id items): the digit comes from the reduced key umin(bits - min, range)
+// (DepthCtl above), which pass this is decides the digit and which of the two ping-pong buffers is the input, and a pass the
+// frame does not need returns at once -- all read from device memory, so the host launches the same four passes every frame.
+struct DepthPass {
+    const DepthCtl *ctl;
+    int pass;            // 0 .. 3
+    uint64_t *buf[2];    // ping-pong buffers; the first ACTIVE pass reads buf[0]
+};
+template <bool DEPTH, int BITS, typename ItemT>
+__device__ __forceinline__ int radix_digit(ItemT item, int shift, uint32_t kmin, uint32_t krange)
+{
+    if constexpr (DEPTH) return (int)((min((uint32_t)(item >> 32) - kmin, krange) >> shift) & 255u);
+    else return (int)((item >> shift) & ((1 << BITS) - 1));
+}
+
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool DEPTH = false>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int32_t *__restrict__ acc,
-                                                         int64_t n, int shift, int sb)
+                                                         int64_t n, int shift, int sb, DepthPass dp)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
+    uint32_t kmin = 0u, krange = 0u;
+    if constexpr (DEPTH) {
+        const DepthCtl c = *dp.ctl;
+        if (dp.pass < c.first) return; // this frame's keys need fewer passes
+        const int rel = dp.pass - c.first;
+        in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
+        shift = 8 * rel;
+        kmin = c.min_bits; krange = c.range;
+    }
     __shared__ int h[RADIX];
     if (threadIdx.x < RADIX) h[threadIdx.x] = 0;
     __syncthreads();
@@ -172,7 +258,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = base + r * 256 + threadIdx.x;
-        if (k < n) atomicAdd(&h[(int)((item[r] >> shift) & (RADIX - 1))], 1);
+        if (k < n) atomicAdd(&h[radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange)], 1);
     }
     __syncthreads();
     if (threadIdx.x < RADIX) {
@@ -227,6 +313,7 @@ struct ScatterCarry {
     const TileRect *rect;   // [n] by id
     TileRect *rect_sorted;  // [n] in output order
     int32_t *cnt_sorted;    // [n] (x1-x0)*(y1-y0) in output order
+    uint32_t *id_sorted;    // [n] Gaussian ids in output order (instead of the 8-byte items: the expansion needs only these)
 };
 
 // FINAL (last pass of the tile partition only): the pass's output IS the sorted list, so instead of the items it writes what
@@ -245,11 +332,11 @@ struct ScatterFinal {
     int id_shift;
 };
 
-template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false>
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ acc,
                                                             int64_t n, int shift, int nb, int sb, bool prefixed, int32_t *__restrict__ zero_acc,
-                                                            int zero_n, ScatterCarry carry, ScatterFinal fin)
+                                                            int zero_n, ScatterCarry carry, ScatterFinal fin, DepthPass dp)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
@@ -277,7 +364,18 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         s_total[tid] = 0;
     }
     // the next pass's accumulators (see radix_hist_kernel) are cleared here: nothing reads them before that pass's histogram
+    // (also by a depth pass that then finds it has nothing to sort)
     for (int z = blockIdx.x * 256 + tid; z < zero_n; z += gridDim.x * 256) zero_acc[z] = 0;
+    uint32_t kmin = 0u, krange = 0u;
+    if constexpr (DEPTH) {
+        const DepthCtl c = *dp.ctl;
+        if (dp.pass < c.first) return;
+        const int rel = dp.pass - c.first;
+        in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
+        out = reinterpret_cast<ItemT *>(dp.buf[(rel + 1) & 1]);
+        shift = 8 * rel;
+        kmin = c.min_bits; krange = c.range;
+    }
     __syncthreads();
 
     // items of each digit in earlier blocks = whole super-blocks (accumulators) + the earlier blocks of the own super-block
@@ -352,7 +450,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
         const bool valid = k < n;
-        const int d = (int)((item[r] >> shift) & (RADIX - 1));
+        const int d = radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange);
         // lanes holding the same digit ("match any"): a lane differs from me in bit b where ballot(bit b) XOR (my bit b
         // replicated) is set; OR over the bits, complement.  Written on 32-bit halves with the replicated bit as one signed
         // bit-field extract, so a digit bit costs 1 extract + 1 compare + 2 xor + 2 or instead of the 9 operations hipcc
@@ -413,7 +511,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
         if (k < n) {
-            const int d = (int)((item[r] >> shift) & (RADIX - 1));
+            const int d = radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange);
             const int slot = s_dstart[d] + s_wcnt[w][d] + rank[r];
             s_items[slot] = item[r];
             if constexpr (CARRY) s_rect[slot] = rc[r];
@@ -428,7 +526,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const int slot = r * 256 + tid;
         if (slot < valid_n) {
             const ItemT it = s_items[slot];
-            const int d = (int)((it >> shift) & (RADIX - 1));
+            const int d = radix_digit<DEPTH, BITS>(it, shift, kmin, krange);
             const int64_t pos = (int64_t)s_gbase[d] + (slot - s_dstart[d]);
             if constexpr (FINAL) {
                 const uint32_t tile = (uint32_t)(it >> fin.id_shift);
@@ -446,6 +544,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
                     fin.edge_pos[e] = (int32_t)pos;
                 }
                 if (rel == s_dcnt[d] - 1) fin.edge_last[e] = (int32_t)tile;
+            } else if constexpr (CARRY) {
+                carry.id_sorted[pos] = (uint32_t)it; // the last depth pass: ids, rectangles and counts leave, not the items
             } else {
                 out[pos] = it;
             }
@@ -526,7 +626,7 @@ __global__ __launch_bounds__(1024) void ranges_fixup_kernel(const int32_t *__res
 // 8-byte stores) and find each item's owner by a 6-step binary search over the wave's 64 offsets in
 // LDS, so a Gaussian covering thousands of tiles costs no more per item than one covering four.
 template <typename ItemT>
-__global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ doff,
+__global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict__ id_sorted, const int32_t *__restrict__ doff,
                                                      const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n,
                                                      int grid_x, int64_t D, int id_shift, int32_t *__restrict__ ranges, int ranges_n,
                                                      int32_t *__restrict__ zero_acc, int zero_n)
@@ -549,8 +649,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
     int next_off = (k0 + 64 < n) ? doff[k0 + 64] : (int)D;
     asm volatile("" : "+v"(next_off));
     if (k < n) {
-        const uint64_t it = sorted[k];
-        id = (uint32_t)it;
+        id = id_sorted[k];
         off = doff[k];
         rc = rect[k]; // rectangles arrive in depth order (carried by the last sort pass); culled Gaussians have empty ones
     }
@@ -585,20 +684,24 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint64_t *__restrict_
 } // namespace
 
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp, int64_t n, int mode,
-                           int32_t *total_out, bool sums_per_256_ready, hipStream_t s)
+                           int32_t *total_out, bool sums_per_256_ready, hipStream_t s, const uint32_t *blk_minmax, void *depth_ctl)
 {
     if (n <= 0) return hipSuccess;
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
     const int nb = (nw + 3) / 4;
     (void)items;
+    DepthCtl *ctl = (DepthCtl *)depth_ctl; // only the id-order scan behind preprocess is asked to fill it
+    const int nblk = (int)gsr_div_up(n, 256);
+    const int force = (gsr_debug_flags & 256) ? 4 : 0; // GSR_DEBUG bit 8: always four depth passes (tests: same order)
     if (mode == 0 && sums_per_256_ready) { // block_tmp already holds one sum per 256 items (preprocess.hip)
-        hipLaunchKernelGGL((scan_final_kernel<0, 4>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+        hipLaunchKernelGGL((scan_final_kernel<0, 4>), dim3(nb + (ctl ? 1 : 0)), dim3(256), 0, s, in, block_tmp, out, n, total_out, blk_minmax, nblk, ctl, force);
     } else if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL((scan_final_kernel<0, 1>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+        hipLaunchKernelGGL((scan_final_kernel<0, 1>), dim3(nb + (ctl ? 1 : 0)), dim3(256), 0, s, in, block_tmp, out, n, total_out, blk_minmax, nblk, ctl, force);
     } else if (mode == 2) {
         hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL((scan_final_kernel<2, 1>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out);
+        hipLaunchKernelGGL((scan_final_kernel<2, 1>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out, (const uint32_t *)nullptr, 0,
+                           (DepthCtl *)nullptr, 0);
     } else {
         return hipErrorInvalidValue;
     }
@@ -620,21 +723,22 @@ static PassGeom pass_geom(int64_t n)
     return g;
 }
 
-template <int BITS, typename ItemT, bool CARRY, bool FINAL>
+template <int BITS, typename ItemT, bool CARRY, bool FINAL, bool DEPTH = false>
 static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int32_t *zero_acc, int zero_n,
-                              const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s)
+                              const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s, const DepthPass &dp = DepthPass{})
 {
     const PassGeom g = pass_geom(n);
+    // (a skipped depth pass leaves its accumulator rows zero: the super-block scan of a many-block pass then scans zeros)
     if (g.small) {
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
         if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
-                           n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
+                           n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb);
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
         if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
-                           shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
+                           shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
     if constexpr (FINAL)
         hipLaunchKernelGGL(ranges_fixup_kernel, dim3(1 << BITS), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, acc, g.nb, 1 << BITS,
@@ -684,25 +788,36 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
     return radix_pass_any<uint64_t, true>((const uint64_t *)in, (uint64_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s);
 }
 
-// The last pass of the depth sort (8-bit digit of 64-bit items) with the rectangle carry.
-hipError_t gsr_launch_depth_last_pass(const uint64_t *in, uint64_t *out, int32_t *hist, int32_t *acc, int64_t n, int shift,
-                                      const TileRect *rect, TileRect *rect_sorted, int32_t *cnt_sorted, hipStream_t s)
+// The depth sort: Gaussians by depth bits, stable from id order.  Four 8-bit passes over the 64-bit (depth bits << 32 | id) items
+// are launched; how many of them this frame's depth range needs is decided on the device (DepthCtl, filled by the id-order scan),
+// the others return at once.  The last pass writes, instead of the sorted items, what the rest of the pipeline reads: the ids,
+// and each Gaussian's tile rectangle and tile count carried to its sorted position.
+hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    const ScatterCarry carry{rect, rect_sorted, cnt_sorted};
-    radix_pass_launch<8, uint64_t, true, false>(in, out, hist, acc, n, shift, nullptr, 0, carry, ScatterFinal{}, s);
+    const int zero_n = (int)gsr_radix_acc_ints(n);
+    const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted};
+    for (int pass = 0; pass < 4; ++pass) {
+        const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}};
+        // pass p accumulates into acc[p & 1] (cleared by preprocess for p = 0) and clears the other one for pass p + 1
+        if (pass < 3)
+            radix_pass_launch<8, uint64_t, false, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, ws.acc[(pass + 1) & 1], zero_n,
+                                                               ScatterCarry{}, ScatterFinal{}, s, dp);
+        else
+            radix_pass_launch<8, uint64_t, true, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, nullptr, 0, carry, ScatterFinal{}, s, dp);
+    }
     return hipGetLastError();
 }
 
-hipError_t gsr_launch_expand(const uint64_t *sorted_depth_items, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,
+hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,
                              int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n,
                              hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
     const dim3 grid((unsigned)gsr_div_up(n, 256));
     if (item_bytes == 4)
-        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
+        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
     else
-        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, sorted_depth_items, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
+        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
     return hipGetLastError();
 }

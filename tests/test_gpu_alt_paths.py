@@ -1,7 +1,8 @@
 """The code paths that sizes pick -- 64-bit tile items (tile bits + id bits > 32: e.g. 1080p with 5 M Gaussians) and the
 4096-item radix chunks of the depth sort (N > 4 M), the scanned super-block rows of radix passes over more than 2048 blocks
 (D > 8.4 M) -- only run at sizes the oracle cannot replay.  GSR_DEBUG bits 5, 6 and 7
-force them at any size, so the oracle comparison covers them too.  The library reads GSR_DEBUG once, hence a subprocess."""
+force them at any size, so the oracle comparison covers them too; bit 8 makes the depth sort run all four of its 8-bit passes
+whatever the frame's depth range (by default the device decides: three for a scene within two octaves of depth).  The library reads GSR_DEBUG once, hence a subprocess."""
 import os
 import subprocess
 import sys
@@ -13,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("flags", [32, 64, 96, 128, 224])
+@pytest.mark.parametrize("flags", [32, 64, 96, 128, 224, 256, 480])
 def test_parity_with_forced_paths(flags):
     env = dict(os.environ, GSR_DEBUG=str(flags), GSR_FUZZ_CASES="48", GSR_NEEDLE_CASES="4")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",

@@ -145,6 +145,27 @@ def test_depth_ties_keep_id_order(oracle, cameras, scenes):
     parity.compare_forward(got, ref)
 
 
+@pytest.mark.parametrize("near,far,n", [(0.25, 90.0, 4000), (3.0, 3.0, 700), (2.0, 7.9, 3000), (1.9, 2.1, 1500), (50.0, 60.0, 300)])
+def test_depth_ranges_and_the_device_side_pass_plan(oracle, cameras, scenes, near, far, n):
+    """The depth sort runs as many 8-bit passes as the frame's depth RANGE needs (decided on the device from the visible
+    minimum / maximum: keys are bits - min).  Scenes spanning nine octaves (four passes), a single depth plane (one pass, all
+    ties -> id order), ranges straddling a power of two (the exponent bit flips inside the range), and far, thin ranges; some
+    Gaussians behind the camera (culled: they sort last) -- point_list must be exact every time."""
+    sc = scenes.synthetic_scene(n, 0.03, 0.5, int(near * 100) + n)
+    rng = np.random.default_rng(n)
+    cam = cameras.nerf_camera(np.eye(4).tolist(), 208, 144, 0.6911112)  # at the origin, looking down -z (NeRF pose convention)
+    depth = rng.uniform(near, far, n).astype(np.float32)
+    depth[::7] = -depth[::7]                                            # behind the camera: culled
+    sc["means"][:, 2] = -depth
+    sc["means"][:, :2] = (rng.uniform(-0.4, 0.4, (n, 2)) * np.abs(depth)[:, None]).astype(np.float32)
+    sc["scales"] *= np.abs(depth)[:, None] / 3.0                       # similar footprint at every depth
+    kw = render_kwargs(sc, cam, width=208, height=144)
+    gsr, got, ref = _both(oracle, kw)
+    parity.compare_forward(got, ref)
+    d = parity.to_np(got[2]["depths"])
+    assert (d > 0).sum() > n // 2 and abs(float(d[d > 0].min()) - near) < 0.2 * near + 0.5 and int(parity.to_np(got[2]["point_list"]).size) > n
+
+
 def test_huge_gaussian_covers_all_tiles(oracle, cameras, scenes):
     sc = scenes.synthetic_scene(50, 0.05, 0.5, 33)
     sc["scales"][0] = 5.0
