@@ -30,7 +30,7 @@ class GsrGeom(C.Structure):
 
 
 class GsrBinning(C.Structure):
-    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp), ("block_masks", vp)]
+    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp), ("block_masks", vp), ("block_order", vp)]
 
 
 class GsrImage(C.Structure):
@@ -65,6 +65,7 @@ EXPORTS = {
     "gsr_geom_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gsr_binning_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "gsr_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "gsr_block_order_ints": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gsr_forward_count": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), vp, C.c_size_t,
                                     C.POINTER(C.c_int64), vp]),
     "gsr_forward_render": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), C.POINTER(GsrBinning),
@@ -112,7 +113,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gsr_abi_version() != 4:
+        if h.gsr_abi_version() != 5:
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -75,13 +75,13 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     # and written only up to each tile's saturation batch, so they are honoured only when every buffer they were derived from
     # or are read against is the forward's own tensor (identity, not equality): a caller who mixes in perturbed means2D /
     # conic_opacity or another run's ranges / n_contrib gets the self-contained block test instead.
-    masks = None
+    masks, order = None, None
     mask_tag = getattr(point_list, "_gsr_block_masks", None)
     if mask_tag is not None:
-        m_t, owners = mask_tag
+        m_t, owners, o_t = mask_tag
         given = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": means2D, "conic_opacity": conic_opacity}
         if all(owners[k]() is given[k] for k in given):
-            masks = m_t
+            masks, order = m_t, o_t      # (the block order rides with the masks: it was derived from them)
     # likewise the forward's d(colour)/d(direction) sums (GsrGeom.sh_dir_grad) ride on its clamped_state tensor: used when shs
     # and means3D are the very tensors that forward read, with the same camera position and degree -- geom_backward_kernel then
     # reads 36 bytes per Gaussian instead of the 192 bytes of coefficients
@@ -112,9 +112,9 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
                         _host.ptr(cl), _host.records_ptr(rec_tag, N, dev), _host.ptr(sh_dir))
     if masks is not None and not (isinstance(masks, torch.Tensor) and masks.dtype == torch.uint8 and masks.device == dev
                                   and masks.numel() == D and masks.is_contiguous()):
-        masks = None
+        masks = order = None
     backward.last_call_used_forward_masks = masks is not None      # for tests and debugging
-    binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks))
+    binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks), _host.ptr(order))
     img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
 
     from . import dist as _dist

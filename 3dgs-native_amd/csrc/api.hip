@@ -260,8 +260,9 @@ void read_tuning()
     std::call_once(g_tuning_once, [] {
         if (const char *e = getenv("GSR_DEBUG")) gsr_debug_flags = atoi(e) & GSR_DEBUG_ALLOWED;
         if (const char *e = getenv("GSR_BWD_BLOCK")) gsr_bwd_block = atoi(e);
-        if (const char *e = getenv("GSR_BWD_XCD")) gsr_bwd_xcd_map = atoi(e) != 0;
+        if (const char *e = getenv("GSR_BWD_XCD")) gsr_bwd_xcd_map = atoi(e);
         if (const char *e = getenv("GSR_FWD_XCD")) gsr_fwd_xcd_map = atoi(e) != 0;
+        if (const char *e = getenv("GSR_BWD_NO_ORDER")) gsr_bwd_no_order = atoi(e) != 0;
     });
 }
 
@@ -320,6 +321,11 @@ const char *gsr_strerror(int code)
 size_t gsr_geom_workspace_bytes(int64_t N) { return gsr_carve_geom(nullptr, N < 0 ? 0 : N).bytes; }
 size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t, int32_t) { return carve_bin(nullptr, N < 0 ? 0 : N, D < 0 ? 0 : D).bytes; }
 size_t gsr_backward_workspace_bytes(int64_t N, int64_t, int32_t, int32_t) { return carve_bwd(nullptr, N < 0 ? 0 : N).bytes; }
+size_t gsr_block_order_ints(int32_t W, int32_t H)
+{
+    if (W <= 0 || H <= 0) return 0;
+    return gsr_bo_ints(((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE));
+}
 
 int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, void *geom_ws, size_t geom_ws_bytes,
                       int64_t *num_rendered, void *stream)
@@ -390,7 +396,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     }
     if (!geom_ok(geom) || !binning->point_list) return GSR_E_NULL;
     if (!geom_aligned(geom) || !gsr_aligned16(geom_ws) || !gsr_aligned16(bin_ws) || !gsr_aligned16(binning->point_list) ||
-        !gsr_aligned16(binning->ranges) || !gsr_aligned16(image->image) || !gsr_aligned16(image->inv_depth) ||
+        !gsr_aligned16(binning->ranges) || !gsr_aligned16(binning->block_order) || !gsr_aligned16(image->image) || !gsr_aligned16(image->inv_depth) ||
         !gsr_aligned16(image->final_T) || !gsr_aligned16(image->n_contrib))
         return GSR_E_ALIGN;
     if (!geom_ws || geom_ws_bytes < gsr_geom_workspace_bytes(N)) return GSR_E_WORKSPACE;
@@ -411,8 +417,11 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     while ((1LL << id_bits) < N) ++id_bits;
     const bool narrow = tb + id_bits <= 32 && !(gsr_debug_flags & 32); // GSR_DEBUG bit 5: 64-bit tile items at any size (tests)
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
+    // the block order (forward -> backward scratch): header cleared here; filed by the blend below unless the image is large
+    int32_t *order = binning->block_masks ? binning->block_order : nullptr;
+    const bool file_order = order && tiles <= GSR_BO_MAX_TILES;
     HIP_TRY(gsr_launch_expand(gw.id_sorted, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
-                              (int)gsr_radix_acc_ints(D), s));
+                              (int)gsr_radix_acc_ints(D), order, order ? GSR_BO_HEADER : 0, file_order ? 1 : 0, s));
     mark(st, 6, s);
     // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible
     //    (12 bits -> 6+6, 13 -> 7+6)
@@ -434,7 +443,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     mark(st, 7, s);
     mark(st, 8, s); // (stage slot "ranges": nothing left in it)
     // 6. blend
-    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, s));
+    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, file_order ? order : nullptr, s));
     mark(st, 9, s);
     return GSR_OK;
 }
@@ -447,6 +456,7 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
     if (!geom || !geom->radii || !geom->xy || !geom->cov3D || !geom->rgb || !geom->conic_opacity || !geom->clamped_state) return GSR_E_NULL;
     if (!binning || !image || !dL_dpixels) return GSR_E_NULL;
     if (!geom_aligned(geom) || !gsr_aligned16(ws) || !gsr_aligned16(binning->point_list) || !gsr_aligned16(binning->ranges) ||
+        !gsr_aligned16(binning->block_masks) || !gsr_aligned16(binning->block_order) ||
         !gsr_aligned16(image->final_T) || !gsr_aligned16(image->n_contrib) || !gsr_aligned16(dL_dpixels) || !gsr_aligned16(payload))
         return GSR_E_ALIGN;
     const int64_t D = binning->D;
@@ -463,7 +473,8 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
         records = bw.rec;
     }
     mark(st, 11, s);
-    if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, binning->block_masks, bw.acc, s));
+    if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, binning->block_masks,
+                                                       binning->block_masks ? binning->block_order : nullptr, bw.acc, s));
     mark(st, 12, s);
     if (payload) HIP_TRY(gsr_launch_view_payload(*scene, cam, *geom, bw.acc, payload, s));
     return GSR_OK;

@@ -22,6 +22,8 @@
 // Differences from the reference in float rounding only: sums over pixels/entries are re-associated
 // (quirk Q15), per-entry constants are factored out of the pixel sums, FMA contraction is on (except in `power`, which is
 // evaluated in the forward's operation order so the replayed alphas are the forward's), and 1/x uses v_rcp_f32 (1 ulp).
+#include <algorithm>
+
 #include "gsr_internal.h"
 
 // This kernel re-associates float sums anyway (quirk Q15), so fused multiply-adds are allowed here.
@@ -43,6 +45,7 @@ __device__ unsigned long long g_bwd_wave[TLB_MAX_WAVES][12];
 // where it ran (HW_ID, XCC_ID) and its s_memrealtime start / end -- so residency per CU is measured on the real code object
 // (the GSR_TIMELINE build needs 94 VGPRs: its waves are capped at 5 per SIMD, the product's 62 are not).  tools/residency.py
 __device__ unsigned long long g_bwd_census[1 << 17][4];
+__device__ const int *g_bwd_order = nullptr; // experiment (tools/residency.py --lpt): launch slot -> block, e.g. longest-lived first
 #define TL_DECL const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
 #define TL(k)
 #define TL_COUNT(k, v)
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                                                                   const float *__restrict__ final_T,
                                                                   const int32_t *__restrict__ n_contrib,
                                                                   const float *__restrict__ dL_dpixels,
-                                                                  const uint8_t *__restrict__ block_masks, GradRec *__restrict__ acc, int dbg, int xcd_map, int n_blocks)
+                                                                  const uint8_t *__restrict__ block_masks, GradRec *__restrict__ acc, int dbg, int xcd_map, int n_blocks,
+                                                                  const int32_t *__restrict__ block_order, int bo_cap)
 {
     constexpr int NPIX = BW * BH;            // pixels of the block this wave owns
     constexpr int PER_TILE = 256 / NPIX;     // blocks per 16x16 tile
@@ -206,12 +210,57 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     // Workgroup ids are handed to the eight XCDs round-robin, so consecutive ids -- the PER_TILE blocks of one tile, which read
     // the same list, masks and records -- land on eight different L2s.  xcd_map != 0: XCD x takes the x-th eighth of the blocks
     // instead, so that a tile's blocks run on ONE XCD, next to each other in its queue (grid = 8 * ceil(blocks / 8)).
+    // xcd_map 2: XCD x takes the tiles t with t % 8 == x (interleaved: every XCD gets the same mix of deep and shallow tiles,
+    // where the bands of map 1 give the XCDs holding the image centre more work than the others).
     int bid = blockIdx.x;
-    if (xcd_map) {
+    const bool ordered = block_order && block_order[GSR_BO_FLAG] != 0; // the forward filed the blocks (it skips large images)
+    if (ordered) {
+    } else if (xcd_map == 1 || block_order) {
         const int per = gridDim.x >> 3;
         bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
         if (bid >= n_blocks) return;
+    } else if (xcd_map == 2) {
+        const int k = blockIdx.x >> 3; // position in this XCD's queue
+        bid = ((k / PER_TILE) * 8 + (blockIdx.x & 7)) * PER_TILE + (k % PER_TILE);
+        if (bid >= n_blocks) return;
     }
+    if (ordered) {
+        // The forward filed every block under (band of its tile, cost class) -- gsr_internal.h "block order".  Launch slot
+        // blockIdx.x runs on XCD blockIdx.x % 8 as the (blockIdx.x / 8)-th workgroup of that XCD's queue: it takes the band's
+        // k-th block counting from the heaviest class down.  Lane c looks at class CLASSES - 1 - c.
+        const int band = blockIdx.x & 7, k = blockIdx.x >> 3;
+        // the band's 512 queues in walking order (class descending, shard ascending): lane l owns positions 8 l .. 8 l + 7
+        int c[8];
+        {
+            const int cls = GSR_BO_CLASSES - 1 - (lane >> 1), sh0 = (lane & 1) * 8;
+            const int4 *cp = reinterpret_cast<const int4 *>(block_order + (band * GSR_BO_CLASSES + cls) * GSR_BO_SHARDS + sh0);
+            const int4 a = cp[0], b = cp[1];
+            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        }
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot += c[j];
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const unsigned long long owner = __ballot(incl > k);
+        if (owner == 0ull) return; // beyond the band's blocks (the grid is rounded up)
+        const int src = __builtin_ctzll(owner);
+        int basej = incl - tot, jj = 0; // every lane searches its own eight; only lane src's answer is used
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (basej + c[j] <= k && jj == j) { basej += c[j]; jj = j + 1; }
+        const int pos = __shfl(8 * lane + jj, src, 64), idx = k - __shfl(basej, src, 64);
+        const int q = (band * GSR_BO_CLASSES + (GSR_BO_CLASSES - 1 - (pos >> 4))) * GSR_BO_SHARDS + (pos & 15);
+        bid = block_order[GSR_BO_HEADER + (size_t)q * bo_cap + idx];
+        bid = __builtin_amdgcn_readfirstlane(bid);
+    }
+#ifdef GSR_CENSUS
+    if (g_bwd_order) bid = g_bwd_order[blockIdx.x];
+#endif
     const int tile = bid / PER_TILE, sub = bid % PER_TILE;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
@@ -451,6 +500,10 @@ hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, h
 }
 
 #ifdef GSR_CENSUS
+extern "C" int gsr_debug_bwd_order(const int *order_dev) // device array [blocks] or NULL
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_order), &order_dev, sizeof(order_dev)) == hipSuccess ? 0 : -1;
+}
 extern "C" int gsr_debug_bwd_census(unsigned long long *out /* [waves][4] */, int waves, int clear)
 {
     if (waves > (1 << 17)) return -1;
@@ -471,22 +524,26 @@ extern "C" int gsr_debug_bwd_phases(unsigned long long *out /* [waves][12] */, i
 #endif
 
 int gsr_bwd_block = 32;
+int gsr_bwd_no_order = 0;  // GSR_BWD_NO_ORDER: ignore the forward's block order (A/B)
 int gsr_bwd_xcd_map = 1;   // GSR_BWD_XCD (see the kernel): on by default, 171 -> 165 us at C3
 int gsr_debug_flags = 0; // see gsr_internal.h
 
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
-                                           const GsrImage &img, const float *dL_dpixels, const uint8_t *block_masks, GradRec *acc,
-                                           hipStream_t s)
+                                           const GsrImage &img, const float *dL_dpixels, const uint8_t *block_masks,
+                                           const int32_t *block_order, GradRec *acc, hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
 #define LAUNCH(BW, BH, M)                                                                                                     \
     do {                                                                                                                      \
         const int nblk = tiles * (256 / ((BW) * (BH)));                                                                       \
-        const int grid = gsr_bwd_xcd_map ? 8 * ((nblk + 7) / 8) : nblk;                                                       \
+        const int ppt = 256 / ((BW) * (BH)); /* map 2 walks whole groups of 8 tiles: grid = 8 * ppt * ceil(tiles / 8) */        \
+        const int32_t *bo = ((M) && (BW) == 8 && (BH) == 4 && !gsr_bwd_no_order) ? block_order : nullptr; /* 8x4 blocks only */    \
+        const int bo_cap = gsr_bo_cap(tiles);                                                                                 \
+        const int grid = bo ? 8 * 8 * gsr_bo_tiles_per_band(tiles) : gsr_bwd_xcd_map == 2 ? 8 * ppt * ((tiles + 7) / 8) : gsr_bwd_xcd_map ? 8 * ((nblk + 7) / 8) : nblk; \
         hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH, M>), dim3(grid), dim3(64), 0, s, cam.W, cam.H, cam.grid_x,    \
                            cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels,  \
-                           block_masks, acc, gsr_debug_flags, gsr_bwd_xcd_map, nblk);                                         \
+                           block_masks, acc, gsr_debug_flags, gsr_bwd_xcd_map, nblk, bo, bo_cap);                             \
     } while (0)
     switch (gsr_bwd_block) { // pixels per wave: GSR_BWD_BLOCK = 32 (8x4, default: measured best at C3), 64 (8x8), 16 (4x4)
     case 16: LAUNCH(4, 4, false); break;

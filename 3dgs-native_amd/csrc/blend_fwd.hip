@@ -99,13 +99,53 @@ struct StagedRec {
     float2 c;
 };
 
+// Block filing for the backward blend (gsr_internal.h "block order"): this wave's two 8x4 blocks (rows 0-3 = lanes 0-31, rows
+// 4-7 = lanes 32-63) go under (band of the tile, cost class, shard), the cost being what the backward's compaction will keep for
+// the block -- the list entries whose mask names it, up to the block's last contributor -- counted from the mask bytes this
+// workgroup wrote (the last staging barrier is behind every wave; same CU, so its L1 serves them).  Kept OUT of line on purpose:
+// inlined -- inside the batch loop or behind it -- its few registers push the kernel past 64 VGPRs, the scheduler then relaxes the
+// walk loop as well (70 VGPRs, 7 workgroups per CU instead of 8) and the kernel goes from 105 to 132 us; as a call made once per
+// wave, with next to nothing live across it, the kernel keeps its 64 VGPRs / 73 SGPRs and needs no scratch.
+__device__ __attribute__((noinline)) void file_blocks(const uint8_t *__restrict__ block_masks, int32_t *__restrict__ block_order, int bo_cap,
+                                                      int n_tiles, int tile, int start, int last)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int kept = last;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) kept = max(kept, __shfl_xor(kept, d, 64)); // per 32-lane half: the block's max n_contrib
+    const int blk = (wv >> 1) * 4 + (wv & 1) + ((lane >> 5) << 1);
+    const unsigned rep = 0x01010101u << blk;                                      // the block's bit in each of four mask bytes
+    const int lo = start, hi = start + kept;
+    int hits = 0;
+    for (int p = (start & ~15) + 16 * (lane & 31); p < hi; p += 16 * 32) {        // 16-byte aligned walk over the bytes [lo, hi)
+        const uint4 v = *reinterpret_cast<const uint4 *>(block_masks + p);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = p + 4 * j;                                              // bytes q .. q + 3: keep those inside [lo, hi)
+            unsigned keep = 0xFFFFFFFFu;
+            if (q < lo) keep &= (lo - q >= 4) ? 0u : (0xFFFFFFFFu << (8 * (lo - q)));
+            if (q + 4 > hi) keep &= (hi - q <= 0) ? 0u : (0xFFFFFFFFu >> (8 * (q + 4 - hi)));
+            hits += __popc(w[j] & rep & keep);
+        }
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
+    if ((lane & 31) == 0) {
+        const int tpb = (n_tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS, band = tile / tpb;
+        const int q = (band * GSR_BO_CLASSES + gsr_bo_class(hits)) * GSR_BO_SHARDS + ((tile - band * tpb) & (GSR_BO_SHARDS - 1));
+        const int pos = atomicAdd(&block_order[q], 1);
+        if (pos < bo_cap) block_order[GSR_BO_HEADER + (size_t)q * bo_cap + pos] = tile * 8 + blk;
+    }
+}
+
 __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int grid_x, float bg0, float bg1, float bg2,
                                                             const int32_t *__restrict__ ranges,
                                                             const int32_t *__restrict__ point_list,
                                                             const BlendRec *__restrict__ rec, float *__restrict__ image,
                                                             float *__restrict__ inv_depth, float *__restrict__ final_T,
                                                             int32_t *__restrict__ n_contrib, uint8_t *__restrict__ block_masks, int xcd_map,
-                                                            int n_tiles)
+                                                            int n_tiles, int32_t *__restrict__ block_order, int bo_cap)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(BATCH + 1) * REC_BYTES]; // + one sentinel record (opacity 0: never valid)
     __shared__ uint8_t s_mask[BATCH];                      // bit k: entry may touch 8x4 block k (k & 1 = x half, k >> 1 = row band)
@@ -295,6 +335,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         image[3 * px + 2] = cb + T * bg2;
         inv_depth[px] = cd;
     }
+    if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, tile, start, last);
     TL(6)
     TL_FLUSH
 }
@@ -324,12 +365,13 @@ extern "C" int gsr_debug_fwd_phases(unsigned long long *out /* [waves][8] */, in
 int gsr_fwd_xcd_map = 0; // GSR_FWD_XCD (see the kernel)
 
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
-                                    const GsrImage &img, uint8_t *block_masks, hipStream_t s)
+                                    const GsrImage &img, uint8_t *block_masks, int32_t *block_order, hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
     const int grid = gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles;
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
-                       ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks, gsr_fwd_xcd_map, tiles);
+                       ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks, gsr_fwd_xcd_map, tiles,
+                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles));
     return hipGetLastError();
 }

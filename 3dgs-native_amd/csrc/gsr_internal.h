@@ -95,9 +95,47 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
 hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
-                             int32_t *zero_acc, int zero_n /* accumulators of the first partition pass, cleared here */, hipStream_t s);
+                             int32_t *zero_acc, int zero_n /* accumulators of the first partition pass, cleared here */,
+                             int32_t *zero_b, int zero_b_n /* the block-order header, or NULL */, int bo_flag /* its `filed` flag */, hipStream_t s);
+// ---- block order (GsrBinning.block_order): the backward blend's 8x4-pixel blocks, heaviest first ---------------------------
+// The backward's waves live 40-90 us of a 165-us kernel, so what starts last decides when the kernel ends.  How many list
+// entries the backward's compaction will keep for a block (mask hits up to the block's last contributor) is the one cheap
+// quantity that ranks the blocks' cost (rank correlation 0.5 with the measured wave life; the tile's list length: 0.2; an
+// oracle order by measured life: 147 us, by this count in 8 classes: 148-150 us, tools/residency.py --lpt).  The forward
+// blend's waves count it for their two blocks when they are done (blend_fwd.hip file_blocks: a call, not inline code -- see
+// there) and file every block under (XCD band of its tile, cost class, shard); the backward blend then walks each band's
+// classes from the heaviest down.  The backward only READS the queues: any number of gsr_backward calls may follow a forward.
+// (Also built and measured: the same filing beside the clearing of the accumulators, in one kernel at the start of
+// gsr_backward -- the filing workgroups' chains of dependent loads crawl under that kernel's 64 MB of stores: 13 -> 36 us at C3,
+// 48 -> 140 us at C5, more than the blend gains.)
+// Layout, int32: [GSR_BO_BANDS][GSR_BO_CLASSES][GSR_BO_SHARDS] counters, a `filed` flag (+ 3 pad) -- written by the forward's expand_kernel --
+// then [GSR_BO_BANDS][GSR_BO_CLASSES][GSR_BO_SHARDS][cap] block ids (tile * 8 + block), cap = 8 * ceil(tiles per band / shards).
+// A (band, class) queue is split over 16 shards by tile (tile % 16) because the filing takes its slot with a RETURNED atomic:
+// 20 000 of them onto 256 addresses serialise at the memory side; onto 4 096 they do not.
+#define GSR_BO_BANDS 8
+#define GSR_BO_CLASSES 32
+#define GSR_BO_SHARDS 16
+#define GSR_BO_QUEUES (GSR_BO_BANDS * GSR_BO_CLASSES * GSR_BO_SHARDS)
+#define GSR_BO_FLAG GSR_BO_QUEUES      // 1: the forward filed the blocks (it does not for images of more than GSR_BO_MAX_TILES tiles)
+#define GSR_BO_HEADER (GSR_BO_QUEUES + 4)
+// Heaviest-first pays while the backward blend runs only a few rounds of waves (800x800: 20 000 blocks on 8 192 wave slots, 2.4
+// rounds, 164 -> 154 us for 5 us more in the forward); at 1920x1080 (65 280 blocks, 8 rounds) the blend gains 2 % and the filing
+// costs the forward more than that, so larger images keep the plain band order.
+#define GSR_BO_MAX_TILES 4096
+static inline int gsr_bo_tiles_per_band(int tiles) { return (tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS; }
+static inline int gsr_bo_cap(int tiles) { return 8 * ((gsr_bo_tiles_per_band(tiles) + GSR_BO_SHARDS - 1) / GSR_BO_SHARDS); }
+static inline size_t gsr_bo_ints(int tiles) { return GSR_BO_HEADER + (size_t)GSR_BO_QUEUES * (size_t)gsr_bo_cap(tiles); }
+// class of a block that keeps `hits` entries: four classes per octave from 8 entries up (class 0: fewer than 8)
+__host__ __device__ static inline int gsr_bo_class(int hits)
+{
+    if (hits < 8) return 0;
+    const int lg = 31 - __builtin_clz((unsigned)hits);          // floor(log2 hits) >= 3
+    const int c = 1 + 4 * (lg - 3) + ((hits >> (lg - 2)) & 3); // two mantissa bits
+    return c < GSR_BO_CLASSES ? c : GSR_BO_CLASSES - 1;
+}
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
-                                    const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */, hipStream_t s);
+                                    const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */,
+                                    int32_t *block_order /* optional out, with block_masks */, hipStream_t s);
 
 // backward
 struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (atomics target)
@@ -106,7 +144,8 @@ struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (
 hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s);
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                            const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
-                                           const uint8_t *block_masks /* optional: the forward's */, GradRec *acc, hipStream_t s);
+                                           const uint8_t *block_masks /* optional: the forward's */,
+                                           const int32_t *block_order /* optional: the forward's, with its masks */, GradRec *acc, hipStream_t s);
 hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc,
                                     const GsrGrads &gr, hipStream_t s);
 
@@ -127,5 +166,6 @@ hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const Gs
 #endif
 extern int gsr_debug_flags;
 extern int gsr_fwd_xcd_map;        // GSR_FWD_XCD: neighbouring tiles of the forward blend on one XCD (blend_fwd.hip)
+extern int gsr_bwd_no_order;
 extern int gsr_bwd_xcd_map;        // GSR_BWD_XCD: a tile's blocks of the backward blend on one XCD (blend_bwd_splat.hip)
 extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)

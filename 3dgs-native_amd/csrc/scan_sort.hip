@@ -629,10 +629,13 @@ template <typename ItemT>
 __global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict__ id_sorted, const int32_t *__restrict__ doff,
                                                      const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n,
                                                      int grid_x, int64_t D, int id_shift, int32_t *__restrict__ ranges, int ranges_n,
-                                                     int32_t *__restrict__ zero_acc, int zero_n)
+                                                     int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ zero_b, int zero_b_n, int bo_flag)
 {
     // the accumulators of the first partition pass (radix_hist_kernel) are cleared here, like the ranges below
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
+    // ... and the counters of the block-order queues the forward blend fills (GsrBinning.block_order)
+    // (and the header's `filed` flag: will the forward blend file them?)
+    for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_b_n; z += (int64_t)gridDim.x * 256) zero_b[z] = (z == GSR_BO_FLAG) ? bo_flag : 0;
     // also clears the tile ranges (filled later by ranges_kernel; untouched tiles must read (0,0)): saves a memset launch
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < ranges_n; z += (int64_t)gridDim.x * 256) ranges[z] = 0;
     __shared__ int s_off[4][64];
@@ -811,13 +814,13 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s)
 
 hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, const TileRect *rect, void *tile_items, int64_t n,
                              int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n,
-                             hipStream_t s)
+                             int32_t *zero_b, int zero_b_n, int bo_flag, hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
     const dim3 grid((unsigned)gsr_div_up(n, 256));
     if (item_bytes == 4)
-        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
+        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag);
     else
-        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n);
+        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag);
     return hipGetLastError();
 }

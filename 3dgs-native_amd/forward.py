@@ -66,8 +66,12 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         if debug:
             print(f"gsr: {W}x{H}, N={N}, D={D}, SH degree {degree}")
         point_list = e((D,), i32)
-        block_masks = e((D,), torch.uint8)     # per-entry 8x4-block hit masks: written by the forward blend, read by backward()
-        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks))
+        # per-entry 8x4-block hit masks: written by the forward blend, read by backward() (allocated with 16 spare bytes: the
+        # backward reads them 16 at a time)
+        block_masks = e((D + 16,), torch.uint8)[:D]
+        # the backward blend's blocks filed by cost, heaviest first (GsrBinning.block_order): filled by the forward blend from the masks
+        block_order = e((int(L.gsr_block_order_ints(W, H)),), i32)
+        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks), _host.ptr(block_order))
         bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
         _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
                                         _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
@@ -85,7 +89,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
             # sh / means3D tensors, this camera position and this degree
             clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(float(v) for v in cam.campos), int(degree))
         owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
-        point_list._gsr_block_masks = (block_masks, {k: weakref.ref(v) for k, v in owners.items()})
+        point_list._gsr_block_masks = (block_masks, {k: weakref.ref(v) for k, v in owners.items()}, block_order)
     return image, depth_image, {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
         "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 #define GSR_TILE 16
 #define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
 #define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
@@ -114,11 +114,18 @@ typedef struct GsrBinning {
     int64_t D;           /* number of (tile, Gaussian) pairs, from gsr_forward_count */
     int32_t *point_list; /* [D] Gaussian ids sorted by (tile, depth bits, id) */
     int32_t *ranges;     /* [tiles*2] (start,end) per tile, (0,0) for untouched tiles */
-    uint8_t *block_masks; /* optional [D], not part of the reference's dict: bit k of byte i = list entry i may reach
+    uint8_t *block_masks; /* optional [D] (allocate D rounded up to a multiple of 16 bytes: they are read 16 at a time), not part of
+                             the reference's dict: bit k of byte i = list entry i may reach
                              alpha >= 1/255 inside 8x4-pixel block k of its tile (k & 1 = x half, k >> 1 = 4-row band).
                              gsr_forward_render writes it (entries up to each tile's saturation point) when not NULL;
                              gsr_backward, given the SAME array back unmodified, compacts each block's list from these
                              bytes instead of re-deriving the test from the records.  NULL on either side is fine. */
+    int32_t *block_order; /* optional [gsr_block_order_ints(W, H)], used only together with block_masks: gsr_forward_render files
+                             every 8x4-pixel block under (XCD band of its tile, cost class), the cost being the number of list
+                             entries the backward will keep for the block; gsr_backward, given the SAME array back unmodified,
+                             starts the heaviest blocks first (its blend kernel's last-started waves decide when it ends:
+                             164 -> 154 us at 800x800 / 1 M Gaussians).  Read-only on the backward side.  Execution order
+                             only: results are the same up to float-atomic order. */
 } GsrBinning;
 
 /* Per-pixel outputs: image, inverse-depth image, dict entries final_Ts / n_contrib. */
@@ -159,6 +166,7 @@ int gsr_build_flags(void);
 size_t gsr_geom_workspace_bytes(int64_t N);
 size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
 size_t gsr_backward_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
+size_t gsr_block_order_ints(int32_t W, int32_t H); /* int32 elements of GsrBinning.block_order for a W x H image */
 
 /* Stage 1 of render_gaussians: wp_preprocess + wp_prefix_sum + the D readback
  * (reference forward.py:719-767), plus the part of the sort that does not depend on D (Gaussians by

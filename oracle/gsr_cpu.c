@@ -247,6 +247,7 @@ int gsr_densify_mark(const GsrParams *p, const float *g, int64_t n, float a, flo
 int gsr_prune_mark(const GsrParams *p, float t, int32_t *v, void *s) { (void)p; (void)t; (void)v; (void)s; return GSR_E_HIP; }
 int gsr_split_removal_mask(int64_t n, int64_t o, const int32_t *m, int32_t *v, void *s) { (void)n; (void)o; (void)m; (void)v; (void)s; return GSR_E_HIP; }
 size_t gsr_mask_scan_workspace_bytes(int64_t N) { (void)N; return 256; }
+size_t gsr_block_order_ints(int32_t W, int32_t H) { (void)W; (void)H; return 4; } /* never written or read on the CPU */
 int gsr_mask_scan(int64_t N, const int32_t *m, int32_t *p, int32_t *c, void *s, size_t b, void *st) { (void)N; (void)m; (void)p; (void)c; (void)s; (void)b; (void)st; return GSR_E_HIP; }
 int gsr_clone_gaussians(const GsrParams *i, const int32_t *m, const int32_t *p, float n, const GsrParams *o, void *s) { (void)i; (void)m; (void)p; (void)n; (void)o; (void)s; return GSR_E_HIP; }
 int gsr_split_gaussians(const GsrParams *i, const int32_t *m, const int32_t *p, int32_t n, float f, const GsrParams *o, void *s) { (void)i; (void)m; (void)p; (void)n; (void)f; (void)o; (void)s; return GSR_E_HIP; }

@@ -88,7 +88,8 @@ int main(int argc, char **argv)
     int64_t D = -1;
     CHECK_GSR(gsr_forward_count(&sc, &cam, &g, geom_ws, geom_bytes, &D, stream));
 
-    GsrBinning bin = {D, dev_alloc(4 * (size_t)D), dev_alloc(8 * (size_t)tiles), dev_alloc((size_t)D)}; /* block_masks: forward -> backward */
+    GsrBinning bin = {D, dev_alloc(4 * (size_t)D), dev_alloc(8 * (size_t)tiles), dev_alloc((size_t)D + 16), /* block_masks: forward -> backward */
+                      dev_alloc(4 * gsr_block_order_ints(W, H))};                                          /* block_order: likewise */
     GsrImage img = {dev_alloc(12 * P), dev_alloc(4 * P), dev_alloc(4 * P), dev_alloc(4 * P)};
     const size_t bin_bytes = gsr_binning_workspace_bytes(N, D, W, H);
     void *bin_ws = dev_alloc(bin_bytes);

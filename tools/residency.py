@@ -85,6 +85,9 @@ for k in ("fwd", "bwd"):
     print(f"   CU finish time as a fraction of the span: p10 {np.percentile((last - t0) / span, 10):.2f} p50 {np.percentile((last - t0) / span, 50):.2f} p90 {np.percentile((last - t0) / span, 90):.2f}")
     start_frac = (r0 - t0) / span
     print(f"   wave start as a fraction of the span: p50 {np.percentile(start_frac, 50):.2f} p90 {np.percentile(start_frac, 90):.2f} p99 {np.percentile(start_frac, 99):.2f} max {start_frac.max():.2f}")
+    # per XCD: when does it run dry, how many waves did it get
+    xk = cu_key >> 12
+    print("   per XCD (waves, finish as a fraction of the span): " + "  ".join(f"{x}: {int((xk == x).sum())} {(r1[xk == x].max() - t0) / span:.2f}" for x in np.unique(xk)))
     # life against the tile's list length (is the tail made of deep tiles?)
     per_tile = 4 if k == "fwd" else 8
     wave_tile = np.flatnonzero(ran) // per_tile
@@ -92,3 +95,88 @@ for k in ("fwd", "bwd"):
     late = r1 > t0 + 0.85 * span
     print(f"   list length of the tile: all waves mean {ll.mean():.0f}; waves still alive after 85 % of the span: {int(late.sum())}, mean list {ll[late].mean() if late.any() else 0:.0f}, mean life {life[late].mean() if late.any() else 0:.1f} us, mean start {start_frac[late].mean() if late.any() else 0:.2f}")
     print(f"   correlation(life, list length) = {np.corrcoef(life, ll)[0, 1]:.2f}")
+
+
+# ---- experiment: what would a longest-lived-first dispatch of the backward's blocks buy?  (--lpt)
+# The measured wave lives of the run above give an ORACLE order; the census build takes it as a launch-slot -> block table.
+if "--lpt" in sys.argv:
+    arr = np.zeros((nw["bwd"], 4), np.uint64)
+    assert fn["bwd"](arr.ctypes.data_as(C.c_void_p), nw["bwd"], 0) == 0
+    life = (arr[:, 2].astype(np.int64) - arr[:, 1].astype(np.int64)).astype(np.float64)
+    nblk = nw["bwd"]
+
+    def timed(order, label):
+        od = torch.as_tensor(order.astype(np.int32)).cuda() if order is not None else None
+        assert L.gsr_debug_bwd_order(C.c_void_p(od.data_ptr() if od is not None else 0)) == 0
+        spans = []
+        for _ in range(4):
+            assert fn["bwd"](None, nw["bwd"], 1) == 0
+            step()
+            torch.cuda.synchronize()
+            a = np.zeros((nw["bwd"], 4), np.uint64)
+            assert fn["bwd"](a.ctypes.data_as(C.c_void_p), nw["bwd"], 0) == 0
+            ok = a[:, 1] > 0
+            spans.append((a[ok, 2].max() - a[ok, 1].min()) / 100.0)
+        print(f"   {label:60s} span us: " + " ".join(f"{x:.1f}" for x in spans))
+        assert L.gsr_debug_bwd_order(C.c_void_p(0)) == 0
+
+    print("== backward blend, dispatch-order experiment (GSR_BWD_XCD as set in the environment applies only to the first line)")
+    timed(None, "as shipped")
+    ident = np.arange(nblk)
+    timed(ident, "identity table (cost of the indirection)")
+    timed(np.argsort(-life, kind="stable"), "longest-lived first, globally")
+    # bands kept: launch slot s runs on XCD s % 8, position s // 8 in its queue; XCD x keeps its band of blocks, longest first
+    per = nblk // 8
+    tab = np.empty(nblk, np.int64)
+    for x in range(8):
+        band = np.arange(x * per, (x + 1) * per)
+        tab[x::8] = band[np.argsort(-life[band], kind="stable")]
+    timed(tab, "longest-lived first inside each XCD's band")
+    tab2 = np.empty(nblk, np.int64)
+    for x in range(8):
+        tab2[x::8] = np.arange(x * per, (x + 1) * per)
+    timed(tab2, "bands, natural order (= GSR_BWD_XCD=1 through the table)")
+    # coarse classes only (what a cheap on-device binning could deliver): 8 classes by life
+    cls = np.minimum(7, (8 * np.argsort(np.argsort(-life)) // nblk))
+    tab3 = np.empty(nblk, np.int64)
+    for x in range(8):
+        band = np.arange(x * per, (x + 1) * per)
+        tab3[x::8] = band[np.argsort(cls[band], kind="stable")]
+    timed(tab3, "8 cost classes inside each band, natural order inside a class")
+
+    # ---- predictors the forward could hand over: how well do they rank the blocks?
+    masks = buf["point_list"]._gsr_block_masks[0].cpu().numpy()
+    ncon = buf["n_contrib"].cpu().numpy()
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    hits_wave = np.zeros(nblk, np.int64)     # mask hits over the 256-entry batches the forward WAVE (8x8 pixels) of the block walks
+    hits_staged = np.zeros(nblk, np.int64)   # mask hits over what the forward staged (whole 256-entry batches up to the tile's last contributor)
+    hits_kept = np.zeros(nblk, np.int64)     # mask hits up to the block's own last contributor (what the backward's compaction keeps)
+    pix_sum = np.zeros(nblk, np.int64)       # sum over the block's pixels of n_contrib
+    for tile in range(gx * gy):
+        ty, tx = divmod(tile, gx)
+        s0, s1 = ranges[tile]
+        nc = ncon[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
+        if s1 <= s0 or nc.size == 0:
+            continue
+        ext = min(s1 - s0, 256 * (int(nc.max()) // 256 + 1))
+        m = masks[s0:s0 + ext]
+        for b in range(8):
+            bx, by = b & 1, b >> 1
+            blk = nc[by * 4:by * 4 + 4, bx * 8:bx * 8 + 8]
+            bit = (m >> b) & 1
+            hits_staged[tile * 8 + b] = int(bit.sum())
+            hits_kept[tile * 8 + b] = int(bit[:int(blk.max()) if blk.size else 0].sum())
+            pix_sum[tile * 8 + b] = int(blk.sum())
+            wv = nc[(by >> 1) * 8:(by >> 1) * 8 + 8, bx * 8:bx * 8 + 8]           # the forward wave's 8x8 block
+            hits_wave[tile * 8 + b] = int(bit[:min(s1 - s0, 256 * (int(wv.max()) // 256 + 1))].sum()) if wv.size else 0
+    rank = lambda v: np.argsort(np.argsort(v))
+    for nm, f in (("mask hits over the batches the forward wave walks", hits_wave), ("the same, in 16 geometric classes (2 per octave)", np.floor(2 * np.log2(np.maximum(1, hits_wave)))),
+                  ("mask hits over the staged batches", hits_staged), ("mask hits up to the block's last contributor", hits_kept),
+                  ("sum of n_contrib over the block's pixels", pix_sum), ("tile list length", np.repeat(list_len, 8))):
+        rho = np.corrcoef(rank(f), rank(life))[0, 1]
+        cls = np.minimum(7, (8 * rank(-f) // nblk))
+        tab = np.empty(nblk, np.int64)
+        for x in range(8):
+            band = np.arange(x * per, (x + 1) * per)
+            tab[x::8] = band[np.argsort(cls[band], kind="stable")]
+        timed(tab, f"8 classes by [{nm}] (rank corr. with life {rho:.2f})")
