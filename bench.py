@@ -47,6 +47,12 @@ SIMDS, MAX_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMD-32, same guide
 # go at half that rate, v_exp / v_rcp / v_log / v_sqrt at a quarter.  tools/valu_rate measures 2.3 / 4.2-4.5 / 8.2 chip-wide with
 # 8 waves per SIMD (profiles/r02_valu_issue_costs.txt); the roof below is priced at the architectural 2 / 4 / 8.
 VALU_ISSUE_CYCLES = {"plain": 2.0, "dpp": 4.0, "transcendental": 8.0}
+# Round 3 (tools/issue_costs, profiles/r03_issue_costs.txt): compares, selects, min/max, VOP3 integer ops and any op with an SGPR
+# operand issue at HALF rate too (4.2-4.3 cycles), plain ops at 2.3.  The SQ counters do not split those classes, so the second
+# figure below prices every vector instruction at the average of its kernel's hot loop, counted from the ISA: the forward's walk
+# is 27 instructions = 19 plain + 7 compare / select / min + 1 exp = 82 cycles; the backward's pixel step 63 = 35 plain + 7
+# compare / select / min + 12 DPP + 2 transcendental (+ 7 others at half rate) = 178 cycles.
+AVG_ISSUE_CYCLES_MEASURED = {"blend_fwd": 82.0 / 27.0, "blend_bwd": 178.0 / 63.0}
 
 
 def roofline_valu(stage, counters, avg_ms):
@@ -63,7 +69,8 @@ def roofline_valu(stage, counters, avg_ms):
     have = SIMDS * avg_ms * 1e-3 * MAX_CLOCK_HZ
     return {"bound": "valu_issue", "kernel": counters.get("kernel"), "wave_instructions": int(insts), "transcendental": int(trans), "dpp": int(dpp),
             "scalar_instructions": int(counters.get("SQ_INSTS_SALU", 0)), "issue_cycles": int(need), "simd_cycles": int(have),
-            "frac": round(need / have, 4), "frac_if_every_op_took_2_cycles": round(insts * 2.0 / have, 4), "avg_ms": round(avg_ms, 4)}
+            "frac": round(need / have, 4), "frac_if_every_op_took_2_cycles": round(insts * 2.0 / have, 4),
+            "frac_at_measured_issue_prices": round(insts * AVG_ISSUE_CYCLES_MEASURED.get(stage, 2.3) / have, 4), "avg_ms": round(avg_ms, 4)}
 
 
 def stage_bytes(N, Nv, D, P, Tn):
