@@ -361,7 +361,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     {
         HIP_TRY(gsr_launch_depth_sort(ws, N, s));
         mark(st, 3, s);
-        HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
+        if (!gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
         mark(st, 4, s);
     }
     HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting

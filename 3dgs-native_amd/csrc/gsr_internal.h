@@ -63,6 +63,8 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
                            bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s,
                            const uint32_t *blk_minmax = nullptr, void *depth_ctl = nullptr /* mode 0: also derive the depth sort's DepthCtl */);
 hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s);
+#define GSR_SMALL_SORT_N 8192          // up to this many Gaussians one workgroup sorts, carries and scans (scan_sort.hip)
+bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes the depth-order offsets (no separate scan)
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
 #define GSR_RADIX_CHUNK 4096
@@ -153,15 +155,16 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
 // GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks, bit 7 the scanned
 // super-block rows of many-block radix passes (radix_superscan_kernel), bit 8 all four depth-sort passes whatever the depth
-// range -- same results by
+// range, bit 9 the 8-Gaussians-per-wave expansion whatever D / N; bit 10 switches the
+// one-workgroup depth stage of small scenes OFF (so small test scenes also run the multi-kernel chain) -- same results by
 // other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
 // one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->
 // libgsr_hip_ablate.so, -DGSR_ABLATE, used by tools/stage_bench.sh) and are compiled out of libgsr_hip.so.
 #ifdef GSR_ABLATE
-#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128 | 256)
+#define GSR_DEBUG_ALLOWED (1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 | 512 | 1024)
 #define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
 #else
-#define GSR_DEBUG_ALLOWED (32 | 64 | 128 | 256)
+#define GSR_DEBUG_ALLOWED (32 | 64 | 128 | 256 | 512 | 1024)
 #define GSR_ABL(flags, bit) false
 #endif
 extern int gsr_debug_flags;

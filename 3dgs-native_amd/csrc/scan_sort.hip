@@ -625,7 +625,10 @@ __global__ __launch_bounds__(1024) void ranges_fixup_kernel(const int32_t *__res
 // [doff[k0], doff[k0+64]) is contiguous.  Lanes walk that range 64 items at a time (fully coalesced
 // 8-byte stores) and find each item's owner by a 6-step binary search over the wave's 64 offsets in
 // LDS, so a Gaussian covering thousands of tiles costs no more per item than one covering four.
-template <typename ItemT>
+// G = Gaussians per wave: 64 when a Gaussian expands to a handful of tiles (C3: 7.75), 8 when it expands to dozens or hundreds
+// (the reference trainer's initial point set: 5 000 Gaussians of scale 0.1 cover 130 tiles each -- at 64 per wave that was 78 waves
+// for 649 k items on a 256-CU chip, 48 us; api.hip picks G from D / N).
+template <typename ItemT, int G>
 __global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict__ id_sorted, const int32_t *__restrict__ doff,
                                                      const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n,
                                                      int grid_x, int64_t D, int id_shift, int32_t *__restrict__ ranges, int ranges_n,
@@ -638,28 +641,30 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict_
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_b_n; z += (int64_t)gridDim.x * 256) zero_b[z] = (z == GSR_BO_FLAG) ? bo_flag : 0;
     // also clears the tile ranges (filled later by ranges_kernel; untouched tiles must read (0,0)): saves a memset launch
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < ranges_n; z += (int64_t)gridDim.x * 256) ranges[z] = 0;
-    __shared__ int s_off[4][64];
-    __shared__ TileRect s_rect[4][64];
-    __shared__ uint32_t s_gid[4][64];
-    __shared__ float s_inv[4][64]; // 1 / (rectangle width in tiles)
+    __shared__ int s_off[4][G];
+    __shared__ TileRect s_rect[4][G];
+    __shared__ uint32_t s_gid[4][G];
+    __shared__ float s_inv[4][G]; // 1 / (rectangle width in tiles)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t k0 = (int64_t)blockIdx.x * 256 + w * 64;
+    const int64_t k0 = ((int64_t)blockIdx.x * 4 + w) * G;
     const int64_t k = k0 + lane;
     int off = (int)D;
     TileRect rc = {0, 0, 0, 0};
     uint32_t id = 0;
     // (requested with the wave's other loads: read where it is used, after the barrier, it was a second serial round trip)
-    int next_off = (k0 + 64 < n) ? doff[k0 + 64] : (int)D;
+    int next_off = (k0 + G < n) ? doff[k0 + G] : (int)D;
     asm volatile("" : "+v"(next_off));
-    if (k < n) {
+    if (lane < G && k < n) {
         id = id_sorted[k];
         off = doff[k];
         rc = rect[k]; // rectangles arrive in depth order (carried by the last sort pass); culled Gaussians have empty ones
     }
-    s_off[w][lane] = off;
-    s_rect[w][lane] = rc;
-    s_gid[w][lane] = id;
-    s_inv[w][lane] = rc.x1 > rc.x0 ? 1.0f / (float)((int)rc.x1 - (int)rc.x0) : 0.0f;
+    if (lane < G) {
+        s_off[w][lane] = off;
+        s_rect[w][lane] = rc;
+        s_gid[w][lane] = id;
+        s_inv[w][lane] = rc.x1 > rc.x0 ? 1.0f / (float)((int)rc.x1 - (int)rc.x0) : 0.0f;
+    }
     __syncthreads();
     if (k0 >= n) return;
     const int begin = s_off[w][0];
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict_
     for (int j = begin + lane; j < end; j += 64) {
         int lo = 0; // last k with off[k] <= j (zero-count Gaussians share their successor's offset)
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1)
+        for (int step = G / 2; step >= 1; step >>= 1)
             if (s_off[w][lo + step] <= j) lo += step;
         const TileRect r = s_rect[w][lo];
         const int t = j - s_off[w][lo];
@@ -681,6 +686,133 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict_
         if (x < 0) { --y; x += wd; }
         else if (x >= wd) { ++y; x -= wd; }
         tile_items[j] = (ItemT)(((ItemT)(uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x) << id_shift) | (ItemT)s_gid[w][lo]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small scenes: the whole depth stage in ONE workgroup
+// ---------------------------------------------------------------------------------------------
+// Up to GSR_SMALL_SORT_N Gaussians (the reference trainer starts with 5 000): ten launches of 5 us each -- four histogram /
+// scatter pairs and the two-kernel depth-order scan -- to order a few thousand items is all latency.  One 1024-thread workgroup
+// does the same stable LSD radix passes with both item buffers in LDS (8-bit digits of the reduced key, only the passes the
+// depth range needs: the extremes are reduced in the kernel itself), then carries rectangle and count to the sorted position and
+// scans the counts into the depth-order offsets.  (A bitonic network over the items -- they are distinct, so their ascending
+// order as 64-bit integers IS the stable order -- was tried first: 91 barrier-separated LDS sweeps on one CU, 85 us.)
+constexpr int SMALL_SORT_MAX = GSR_SMALL_SORT_N;
+constexpr int SMALL_ROUNDS = SMALL_SORT_MAX / 1024; // items per thread
+__global__ __launch_bounds__(1024) void depth_sort_small_kernel(const uint64_t *__restrict__ items, int n, const TileRect *__restrict__ rect,
+                                                                uint32_t *__restrict__ id_sorted, TileRect *__restrict__ rect_sorted,
+                                                                int32_t *__restrict__ cnt_sorted, int32_t *__restrict__ doff)
+{
+    __shared__ uint64_t s_buf[2][SMALL_SORT_MAX];
+    __shared__ int s_wcnt[16][256]; // per-wave digit counts -> per-wave start offsets within the digit
+    __shared__ int s_dstart[256];   // first slot of each digit
+    __shared__ uint32_t s_lo[16], s_hi[16];
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // load + the visible depth range (culled items carry 0xFFFFFFFF: they end up last, in id order)
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = tid; i < SMALL_SORT_MAX; i += 1024) {
+        const uint64_t it = i < n ? items[i] : ~0ull;
+        s_buf[0][i] = it;
+        const uint32_t bits = (uint32_t)(it >> 32);
+        if (bits != 0xFFFFFFFFu) { lo = min(lo, bits); hi = max(hi, bits); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+    }
+    if (lane == 0) { s_lo[w] = lo; s_hi[w] = hi; }
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) { lo = min(lo, s_lo[k]); hi = max(hi, s_hi[k]); }
+    const uint32_t kmin = lo > hi ? 0xFFFFFFFFu : lo, krange = lo > hi ? 0u : hi - lo + 1u;
+    const int npass = max(1, (32 - __builtin_clz(krange | 1u) + 7) / 8);
+    const int per_wave = SMALL_SORT_MAX / 16; // each wave owns 512 consecutive slots, walked in rounds of 64 (index order)
+    int cur = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = 8 * pass;
+        for (int d = tid; d < 16 * 256; d += 1024) (&s_wcnt[0][0])[d] = 0;
+        __syncthreads();
+        int rank[SMALL_ROUNDS], dig[SMALL_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < SMALL_ROUNDS; ++r) {
+            const int i = w * per_wave + r * 64 + lane;
+            const bool valid = i < n;
+            const int d = radix_digit<true, 8>(s_buf[cur][i], shift, kmin, krange);
+            unsigned int diff_lo = 0u, diff_hi = 0u;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned int rep = (unsigned int)__builtin_amdgcn_sbfe(d, b, 1);
+                const unsigned long long mm = __ballot(rep != 0u);
+                diff_lo |= (unsigned int)mm ^ rep;
+                diff_hi |= (unsigned int)(mm >> 32) ^ rep;
+            }
+            unsigned long long peers = ~(((unsigned long long)diff_hi << 32) | diff_lo) & __ballot(valid);
+            if (!valid) peers = 0ull;
+            const int before = __popcll(peers & lt_mask);
+            const int old = valid ? s_wcnt[w][d] : 0;
+            if (valid && before == 0) s_wcnt[w][d] = old + __popcll(peers);
+            rank[r] = old + before;
+            dig[r] = d;
+        }
+        __syncthreads();
+        // per digit: prefix over the 16 waves, then an exclusive scan over the digits (threads 0 .. 255 = 4 waves)
+        int run = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int c = s_wcnt[k][tid];
+                s_wcnt[k][tid] = run;
+                run += c;
+            }
+        }
+        const int incl = wave_incl_scan(run);
+        if (tid < 256 && lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        if (tid < 256) {
+            int base = incl - run;
+            for (int k = 0; k < w; ++k) base += s_wsum[k];
+            s_dstart[tid] = base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SMALL_ROUNDS; ++r) {
+            const int i = w * per_wave + r * 64 + lane;
+            if (i < n) s_buf[cur ^ 1][s_dstart[dig[r]] + s_wcnt[w][dig[r]] + rank[r]] = s_buf[cur][i];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // carry + exclusive scan of the tile counts in sorted order: thread t owns the positions [t * per, t * per + per)
+    const int per = (n + 1023) >> 10;
+    int cnt[SMALL_ROUNDS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < SMALL_ROUNDS; ++q) {
+        const int pos = tid * per + q;
+        cnt[q] = 0;
+        if (q < per && pos < n) {
+            const uint32_t id = (uint32_t)s_buf[cur][pos];
+            const unsigned long long r = reinterpret_cast<const unsigned long long *>(rect)[id];
+            const int x0 = (int)(r & 0xFFFF), y0 = (int)((r >> 16) & 0xFFFF), x1 = (int)((r >> 32) & 0xFFFF), y1 = (int)(r >> 48);
+            cnt[q] = (x1 - x0) * (y1 - y0);
+            id_sorted[pos] = id;
+            reinterpret_cast<unsigned long long *>(rect_sorted)[pos] = r;
+            cnt_sorted[pos] = cnt[q];
+        }
+        sum += cnt[q];
+    }
+    const int incl = wave_incl_scan(sum);
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int k = 0; k < w; ++k) base += s_wsum[k];
+#pragma unroll
+    for (int q = 0; q < SMALL_ROUNDS; ++q) {
+        const int pos = tid * per + q;
+        if (q < per && pos < n) doff[pos] = base;
+        base += cnt[q];
     }
 }
 
@@ -795,9 +927,16 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
 // are launched; how many of them this frame's depth range needs is decided on the device (DepthCtl, filled by the id-order scan),
 // the others return at once.  The last pass writes, instead of the sorted items, what the rest of the pipeline reads: the ids,
 // and each Gaussian's tile rectangle and tile count carried to its sorted position.
+bool gsr_small_depth_path(int64_t n) { return n <= GSR_SMALL_SORT_N && !(gsr_debug_flags & 1024); } // GSR_DEBUG bit 10: never (tests)
+
 hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
+    if (gsr_small_depth_path(n)) { // sorts, carries AND scans: the caller skips the depth-order scan
+        hipLaunchKernelGGL(depth_sort_small_kernel, dim3(1), dim3(1024), 0, s, ws.depth_item, (int)n, ws.rect, ws.id_sorted, ws.rect_sorted,
+                           ws.cnt_sorted, ws.doff);
+        return hipGetLastError();
+    }
     const int zero_n = (int)gsr_radix_acc_ints(n);
     const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted};
     for (int pass = 0; pass < 4; ++pass) {
@@ -817,10 +956,12 @@ hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, con
                              int32_t *zero_b, int zero_b_n, int bo_flag, hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
-    const dim3 grid((unsigned)gsr_div_up(n, 256));
-    if (item_bytes == 4)
-        hipLaunchKernelGGL(expand_kernel<uint32_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint32_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag);
-    else
-        hipLaunchKernelGGL(expand_kernel<uint64_t>, grid, dim3(256), 0, s, id_sorted, doff, rect, (uint64_t *)tile_items, n, grid_x, D, id_shift, ranges, ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag);
+    const bool few = D / n >= 32 || (gsr_debug_flags & 512); // GSR_DEBUG bit 9: the 8-per-wave expansion at any size (tests)
+#define EXPAND(T, G)                                                                                                          \
+    hipLaunchKernelGGL((expand_kernel<T, G>), dim3((unsigned)gsr_div_up(n, 4 * (G))), dim3(256), 0, s, id_sorted, doff, rect, (T *)tile_items, n, grid_x, D, \
+                       id_shift, ranges, ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag)
+    if (item_bytes == 4) { if (few) EXPAND(uint32_t, 8); else EXPAND(uint32_t, 64); }
+    else { if (few) EXPAND(uint64_t, 8); else EXPAND(uint64_t, 64); }
+#undef EXPAND
     return hipGetLastError();
 }

@@ -227,7 +227,7 @@ def test_product_build_has_no_ablation_switches(libpath):
     product_flags = re.search(r"^CXXFLAGS = (.*(?:\\\n.*)*)", mk, re.M).group(1)
     assert "GSR_ABLATE" not in product_flags and "-DGSR_ABLATE" in mk
     hdr = open(os.path.join(ROOT, PKG_NAME, "csrc", "gsr_internal.h")).read()
-    assert "#define GSR_ABL(flags, bit) false" in hdr and "#define GSR_DEBUG_ALLOWED (32 | 64 | 128 | 256)" in hdr
+    assert "#define GSR_ABL(flags, bit) false" in hdr and "#define GSR_DEBUG_ALLOWED (32 | 64 | 128 | 256 | 512 | 1024)" in hdr
     for f in ("blend_bwd_splat.hip", "preprocess.hip"):      # every use of the kernels' debug word goes through GSR_ABL
         src = open(os.path.join(ROOT, PKG_NAME, "csrc", f)).read()
         assert not re.search(r"\bdbg\s*&", src), f

@@ -14,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("flags", [32, 64, 96, 128, 224, 256, 480])
+@pytest.mark.parametrize("flags", [32, 64, 96, 128, 224, 256, 512, 1024, 1248, 2016])
 def test_parity_with_forced_paths(flags):
     env = dict(os.environ, GSR_DEBUG=str(flags), GSR_FUZZ_CASES="48", GSR_NEEDLE_CASES="4")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
