@@ -76,6 +76,10 @@ def workspace_written(t):
     _ws_generation[id(t)] = _ws_generation.get(id(t), 0) + 1
 
 
+def generation_of(t):
+    return _ws_generation.get(id(t), 0)
+
+
 def tag_records(ws_tensor, n):
     return (ws_tensor, _ws_generation.get(id(ws_tensor), 0), n)
 

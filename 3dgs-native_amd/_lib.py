@@ -30,7 +30,8 @@ class GsrGeom(C.Structure):
 
 
 class GsrBinning(C.Structure):
-    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp), ("block_masks", vp), ("block_order", vp)]
+    _fields_ = [("D", C.c_int64), ("point_list", vp), ("ranges", vp), ("block_masks", vp), ("block_order", vp), ("backward_ws", vp),
+                ("backward_ws_cleared", C.c_int32)]
 
 
 class GsrImage(C.Structure):
@@ -113,7 +114,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gsr_abi_version() != 5:
+        if h.gsr_abi_version() != 6:
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib

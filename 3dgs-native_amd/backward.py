@@ -76,6 +76,7 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     # or are read against is the forward's own tensor (identity, not equality): a caller who mixes in perturbed means2D /
     # conic_opacity or another run's ranges / n_contrib gets the self-contained block test instead.
     masks, order = None, None
+    cleared_tag = getattr(point_list, "_gsr_cleared_ws", None)     # "the forward cleared the backward workspace's accumulators"
     mask_tag = getattr(point_list, "_gsr_block_masks", None)
     if mask_tag is not None:
         m_t, owners, o_t = mask_tag
@@ -114,7 +115,6 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
                                   and masks.numel() == D and masks.is_contiguous()):
         masks = order = None
     backward.last_call_used_forward_masks = masks is not None      # for tests and debugging
-    binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks), _host.ptr(order))
     img = _lib.GsrImage(None, None, _host.ptr(final_Ts), _host.ptr(n_contrib))
 
     from . import dist as _dist
@@ -142,6 +142,13 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
                           _host.ptr(dL_dsh), _host.ptr(dL_dcolor), _host.ptr(dL_dmean2D), _host.ptr(dL_dconic), _host.ptr(payload))
     with torch.cuda.device(dev):
         ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
+        # the forward cleared this workspace's accumulators in its blend kernel, and no backward has used it since?
+        cleared = (cleared_tag is not None and cleared_tag[0] is ws and cleared_tag[2] == N
+                   and _host.generation_of(ws) == cleared_tag[1])
+        _host.workspace_written(ws)                     # ... it is used now
+        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks), _host.ptr(order),
+                                  _host.ptr(ws) if cleared else None, 1 if cleared else 0)
+        backward.last_call_skipped_the_clear = cleared     # for tests and debugging
         if on_payload is not None and payload is not None:
             # two halves: the view payload is complete after the blend half, so the caller's hook can start its exchange
             # (an asynchronous all-gather) while the per-Gaussian half still runs

@@ -443,7 +443,17 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     mark(st, 7, s);
     mark(st, 8, s); // (stage slot "ranges": nothing left in it)
     // 6. blend
-    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, file_order ? order : nullptr, s));
+        // the backward's accumulator records are cleared by the blend kernel's spare workgroups when the caller hands its backward
+    // workspace over (GsrBinning.backward_ws); it then tells gsr_backward so (GsrBinning.backward_ws_cleared)
+    void *clear = nullptr;
+    size_t clear_bytes = 0;
+    if (binning->backward_ws) {
+        if (!gsr_aligned16(binning->backward_ws)) return GSR_E_ALIGN;
+        clear = carve_bwd(binning->backward_ws, N).acc;
+        clear_bytes = sizeof(GradRec) * (size_t)N;
+    }
+    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, file_order ? order : nullptr,
+                                     clear, clear_bytes, s));
     mark(st, 9, s);
     return GSR_OK;
 }
@@ -466,7 +476,8 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
     const CamK cam = make_cam(camera);
     const BwdWs bw = carve_bwd(ws, N);
     mark(st, 10, s);
-    HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
+    // (unless gsr_forward_render cleared this very workspace's accumulators in its blend kernel and nothing has used it since)
+    if (!(binning->backward_ws_cleared && binning->backward_ws == ws)) HIP_TRY(hipMemsetAsync(bw.acc, 0, sizeof(GradRec) * (size_t)N, s));
     const BlendRec *records = (const BlendRec *)geom->blend_records;
     if (D > 0 && !records) {
         HIP_TRY(gsr_launch_pack_records(*geom, bw.rec, N, s));

@@ -24,6 +24,8 @@
 // (v_permlane32_swap hand-over of 1 - alpha): bit-identical results, but splats at C3 are as large as the blocks, so the finer
 // blocks cull almost nothing (168 live entries per 8x4 block against 168 per 8x8 block) and the pair step costs 28 vector
 // instructions against 2 x 22: 0.149 ms against 0.128 ms.
+#include <algorithm>
+
 #include "gsr_internal.h"
 
 // GSR_TIMELINE (diagnostic build only, never the product): per-phase shader-cycle totals over all waves
@@ -145,8 +147,19 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
                                                             const BlendRec *__restrict__ rec, float *__restrict__ image,
                                                             float *__restrict__ inv_depth, float *__restrict__ final_T,
                                                             int32_t *__restrict__ n_contrib, uint8_t *__restrict__ block_masks, int xcd_map,
-                                                            int n_tiles, int32_t *__restrict__ block_order, int bo_cap)
+                                                            int n_tiles, int32_t *__restrict__ block_order, int bo_cap,
+                                                            float4 *__restrict__ clear4, long long clear_n4, int clear_wgs)
 {
+    // Spare workgroups behind the tiles' (clear_wgs of them, when the caller handed over its backward workspace): they clear the
+    // backward's accumulator records.  They are dispatched after every tile's workgroup, i.e. as the kernel starts to drain and
+    // CUs fall idle, and the blend hardly uses HBM -- the 64 MB the backward used to clear in a launch of its own (12 us at C3,
+    // 48 us at C5) cost next to nothing here.
+    if (clear_wgs > 0 && (int)blockIdx.x >= (int)gridDim.x - clear_wgs) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long i = ((long long)blockIdx.x - ((long long)gridDim.x - clear_wgs)) * 256 + threadIdx.x; i < clear_n4; i += (long long)clear_wgs * 256)
+            clear4[i] = z;
+        return;
+    }
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(BATCH + 1) * REC_BYTES]; // + one sentinel record (opacity 0: never valid)
     __shared__ uint8_t s_mask[BATCH];                      // bit k: entry may touch 8x4 block k (k & 1 = x half, k >> 1 = row band)
     __shared__ uint16_t s_list[NWAVES][BATCH + LIST_PAD];  // per wave: byte offsets (into s_rec) of its live entries, in list order
@@ -365,13 +378,16 @@ extern "C" int gsr_debug_fwd_phases(unsigned long long *out /* [waves][8] */, in
 int gsr_fwd_xcd_map = 0; // GSR_FWD_XCD (see the kernel)
 
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
-                                    const GsrImage &img, uint8_t *block_masks, int32_t *block_order, hipStream_t s)
+                                    const GsrImage &img, uint8_t *block_masks, int32_t *block_order, void *clear, size_t clear_bytes,
+                                    hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
-    const int grid = gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles;
+    const long long clear_n4 = (clear && !gsr_fwd_xcd_map) ? (long long)(clear_bytes / 16) : 0;
+    const int clear_wgs = (int)std::min<long long>(2048, (clear_n4 + 255) / 256);
+    const int grid = (gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles) + clear_wgs;
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
                        ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks, gsr_fwd_xcd_map, tiles,
-                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles));
+                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles), reinterpret_cast<float4 *>(clear), clear_n4, clear_wgs);
     return hipGetLastError();
 }

@@ -137,7 +137,8 @@ __host__ __device__ static inline int gsr_bo_class(int hits)
 }
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                     const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */,
-                                    int32_t *block_order /* optional out, with block_masks */, hipStream_t s);
+                                    int32_t *block_order /* optional out, with block_masks */,
+                                    void *clear, size_t clear_bytes /* optional: memory its spare workgroups zero (16-byte units) */, hipStream_t s);
 
 // backward
 struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (atomics target)

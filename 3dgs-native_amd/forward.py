@@ -12,6 +12,10 @@ import torch
 from . import _host, _lib
 from .config import TILE_M, TILE_N
 
+# Training use (the default): the forward blend kernel's spare workgroups clear the accumulators of the backward workspace while
+# that kernel drains, so the backward() that follows does not start with a 64-byte-per-Gaussian clear of its own.  A render-only
+# user can switch it off (it allocates the backward's scratch): forward.PRECLEAR_BACKWARD = False.
+PRECLEAR_BACKWARD = not bool(int(os.environ.get("GSR_NO_PRECLEAR", "0")))
 _NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))   # A/B switch: backward reads the SH rows itself (same results)
 
 
@@ -71,7 +75,12 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         block_masks = e((D + 16,), torch.uint8)[:D]
         # the backward blend's blocks filed by cost, heaviest first (GsrBinning.block_order): filled by the forward blend from the masks
         block_order = e((int(L.gsr_block_order_ints(W, H)),), i32)
-        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks), _host.ptr(block_order))
+        bwd_ws = None
+        if PRECLEAR_BACKWARD and N > 0 and D > 0:
+            bwd_ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
+            _host.workspace_written(bwd_ws)
+        binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks), _host.ptr(block_order),
+                                  _host.ptr(bwd_ws), 0)
         bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
         _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
                                         _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
@@ -90,6 +99,8 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
             clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(float(v) for v in cam.campos), int(degree))
         owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
         point_list._gsr_block_masks = (block_masks, {k: weakref.ref(v) for k, v in owners.items()}, block_order)
+        if bwd_ws is not None:      # "this backward workspace has clean accumulators as of this generation" (backward() checks)
+            point_list._gsr_cleared_ws = _host.tag_records(bwd_ws, N)
     return image, depth_image, {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
         "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 #define GSR_TILE 16
 #define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
 #define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
@@ -126,6 +126,12 @@ typedef struct GsrBinning {
                              starts the heaviest blocks first (its blend kernel's last-started waves decide when it ends:
                              164 -> 154 us at 800x800 / 1 M Gaussians).  Read-only on the backward side.  Execution order
                              only: results are the same up to float-atomic order. */
+    void *backward_ws;    /* optional: the workspace the caller will give gsr_backward (>= gsr_backward_workspace_bytes).  Handed to
+                             gsr_forward_render, the forward blend kernel's spare workgroups clear the accumulator records in it
+                             while that kernel drains -- the 64 bytes per Gaussian gsr_backward otherwise clears in a launch of
+                             its own (12 us at 1 M Gaussians). */
+    int32_t backward_ws_cleared; /* gsr_backward only: non-zero = `ws` is that `backward_ws`, and nothing has written to it since the
+                             gsr_forward_render that cleared it (no other gsr_backward in particular): the clear is skipped */
 } GsrBinning;
 
 /* Per-pixel outputs: image, inverse-depth image, dict entries final_Ts / n_contrib. */

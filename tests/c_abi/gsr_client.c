@@ -88,8 +88,14 @@ int main(int argc, char **argv)
     int64_t D = -1;
     CHECK_GSR(gsr_forward_count(&sc, &cam, &g, geom_ws, geom_bytes, &D, stream));
 
+    const size_t bwd_bytes = gsr_backward_workspace_bytes(N, D, W, H);
+    void *bwd_ws = dev_alloc(bwd_bytes);
     GsrBinning bin = {D, dev_alloc(4 * (size_t)D), dev_alloc(8 * (size_t)tiles), dev_alloc((size_t)D + 16), /* block_masks: forward -> backward */
-                      dev_alloc(4 * gsr_block_order_ints(W, H))};                                          /* block_order: likewise */
+                      dev_alloc(4 * gsr_block_order_ints(W, H)),                                           /* block_order: likewise */
+                      NULL, 0};
+#ifndef GSR_CLIENT_CPU
+    bin.backward_ws = bwd_ws; /* the forward blend's spare workgroups clear the backward's accumulators in it */
+#endif
     GsrImage img = {dev_alloc(12 * P), dev_alloc(4 * P), dev_alloc(4 * P), dev_alloc(4 * P)};
     const size_t bin_bytes = gsr_binning_workspace_bytes(N, D, W, H);
     void *bin_ws = dev_alloc(bin_bytes);
@@ -97,10 +103,9 @@ int main(int argc, char **argv)
 
     GsrGrads gr = {dev_alloc(12 * n), dev_alloc(12 * n), dev_alloc(16 * n), dev_alloc(4 * n), dev_alloc(192 * n), dev_alloc(12 * n),
                    dev_alloc(12 * n), dev_alloc(16 * n), NULL};
-    const size_t bwd_bytes = gsr_backward_workspace_bytes(N, D, W, H);
-    void *bwd_ws = dev_alloc(bwd_bytes);
 #ifndef GSR_CLIENT_CPU
     g.blend_records = geom_ws; /* still untouched: the backward reuses the forward's records */
+    bin.backward_ws_cleared = 1; /* ... and bwd_ws has not been touched since gsr_forward_render cleared its accumulators */
 #endif
     CHECK_GSR(gsr_backward(&sc, &cam, &g, &bin, &img, dpix, &gr, bwd_ws, bwd_bytes, stream));
     CHECK_HIP(hipStreamSynchronize(stream));

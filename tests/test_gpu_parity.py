@@ -343,6 +343,35 @@ def test_sh_direction_sums_handed_from_forward_to_backward(oracle, cameras, scen
                 np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()), err_msg=f"{swap} {k}")
 
 
+def test_backward_accumulators_cleared_by_the_forward(oracle, cameras, scenes):
+    """GsrBinning.backward_ws: the forward blend kernel's spare workgroups clear the backward's accumulators, and the backward()
+    that follows skips its own clear -- once: a second backward() on the same forward, a backward() after another forward's
+    backward, or one with a foreign point_list must clear for itself.  Every one of them has to give the oracle's gradients."""
+    import torch
+    gsr = pkg()
+    from conftest import sub
+    bwd = sub("backward").backward
+    sc = scenes.synthetic_scene(6000, 0.05, 0.6, 77)
+    cam = lego_camera(cameras, frame=6, width=192, height=160)
+    kw = render_kwargs(sc, cam, width=192, height=160)
+    ref = oracle.render_gaussians(**kw)
+    dpix = _pixel_grad(160, 192)
+    g_ref = oracle.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix))
+    buf_a = gsr.render_gaussians(**kw)[2]
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_a, dpix)), g_ref)
+    assert bwd.last_call_skipped_the_clear
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_a, dpix)), g_ref)      # the same forward again
+    assert not bwd.last_call_skipped_the_clear
+    buf_b = gsr.render_gaussians(**kw)[2]
+    buf_c = gsr.render_gaussians(**kw)[2]                                                       # clears the workspace again
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_b, dpix)), g_ref)      # an older forward's buffers: stale tag
+    assert not bwd.last_call_skipped_the_clear
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_c, dpix)), g_ref)      # its own were dirtied by the call above
+    assert not bwd.last_call_skipped_the_clear
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix)), g_ref)     # the oracle's (numpy) buffers
+    assert not bwd.last_call_skipped_the_clear
+
+
 def test_dL_dcov3D_is_a_dense_zero_array(cameras, scenes):
     """backward.py:1119 returns an (N, 6) zero array; ours must behave like one (dense strides, .view(-1), numpy)."""
     gsr = pkg()
