@@ -277,8 +277,8 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.depth_item = c.take<uint64_t>((size_t)N);
     w.sort_tmp = c.take<uint64_t>((size_t)N);
     w.id_sorted = c.take<uint32_t>((size_t)N);
-    w.blk_minmax = c.take<uint32_t>(2 * (size_t)gsr_div_up(N, 256) + 4);
-    w.depth_ctl = c.take<uint32_t>(4);
+    w.blk_minmax = c.take<uint32_t>(4 * (size_t)gsr_div_up(N, 256) + 4);
+    w.depth_ctl = c.take<uint32_t>(8);
     w.rect_sorted = c.take<TileRect>((size_t)N);
     w.cnt_sorted = c.take<int32_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);

@@ -40,7 +40,7 @@ struct GeomWs {
     uint64_t *depth_item; // [N] (depth bits << 32 | id), 0xFFFFFFFF depth for culled: the depth sort's input
     uint64_t *sort_tmp;   // [N] ping-pong partner of depth_item
     uint32_t *id_sorted;  // [N] Gaussian ids in depth order (written by the last depth-sort pass)
-    uint32_t *blk_minmax; // [2 * ceil(N / 256)] smallest / largest visible depth bits per preprocess block
+    uint32_t *blk_minmax; // [4 * ceil(N / 256)] per preprocess block: smallest / largest visible depth bits, visible count, -
     void *depth_ctl;      // DepthCtl (scan_sort.hip): this frame's depth range and pass count, decided on the device
     TileRect *rect_sorted; // [N] tile rectangles in depth order (written by the last depth-sort pass)
     int32_t *cnt_sorted;  // [N] tile counts in depth order (same pass)

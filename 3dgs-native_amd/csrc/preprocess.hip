@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float *__restrict__ sh_dir_grad, uint32_t *__restrict__ blk_minmax, int dbg)
 {
     __shared__ int s_tiles[4];
-    __shared__ uint32_t s_dmin[4], s_dmax[4];
+    __shared__ uint32_t s_dmin[4], s_dmax[4], s_dvis[4];
     // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
     for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
     // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
             lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
             hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
         }
-        if (lane == 0) { s_dmin[wv] = lo; s_dmax[wv] = hi; }
+        const unsigned long long vis_bits = __ballot(visible && in_range);
+        if (lane == 0) { s_dmin[wv] = lo; s_dmax[wv] = hi; s_dvis[wv] = (uint32_t)__popcll(vis_bits); }
     }
     sh_rows_commit(sh_regs, lds_wave, lane);
     // in_range: tail lanes redo the last Gaussian; their rows do not exist (found by tests/test_gpu_fuzz.py: N = 1, one big
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     __syncthreads(); // SH rows have landed in LDS
     if (threadIdx.x == 0) {
         block_tile_sums[blockIdx.x] = s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3];
-        reinterpret_cast<uint2 *>(blk_minmax)[blockIdx.x] = make_uint2(min(min(s_dmin[0], s_dmin[1]), min(s_dmin[2], s_dmin[3])),
-                                                                       max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3])));
+        reinterpret_cast<uint4 *>(blk_minmax)[blockIdx.x] = make_uint4(min(min(s_dmin[0], s_dmin[1]), min(s_dmin[2], s_dmin[3])),
+                                                                       max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3])),
+                                                                       s_dvis[0] + s_dvis[1] + s_dvis[2] + s_dvis[3], 0u);
     }
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian

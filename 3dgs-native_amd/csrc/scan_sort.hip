@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 struct DepthCtl {
     uint32_t min_bits, range;
     int32_t npass, first; // passes 0 .. 3 are launched; pass p sorts digit p - first, passes below `first` = 4 - npass exit at once
+    int32_t n_vis;        // visible Gaussians: the first active pass drops the culled ones, the later passes move n_vis items
+    int32_t pad[3];
 };
 
 // Run by ONE wave of the id-order scan (which follows preprocess in the stream and precedes the depth passes): preprocess left
@@ -104,37 +106,38 @@ __device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict
     // one 256-thread workgroup; 16-byte loads (two blocks each), all of a thread's loads in flight before anything is combined:
     // 8 bytes x N / 256 (31 KB at a million Gaussians) in one or two memory round trips
     __shared__ uint32_t s_lo[4], s_hi[4];
+    __shared__ int s_nv[4];
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    const int npair = nblk >> 1;
-    const uint4 *p4 = reinterpret_cast<const uint4 *>(blk_minmax);
-    for (int b0 = 0; b0 < npair; b0 += 256 * 8) {
+    int nv = 0;
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(blk_minmax); // per block {min, max, visible count, -}
+    for (int b0 = 0; b0 < nblk; b0 += 256 * 8) {
         uint4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int b = b0 + k * 256 + (int)threadIdx.x;
-            v[k] = b < npair ? p4[b] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+            v[k] = b < nblk ? p4[b] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            lo = min(lo, min(v[k].x, v[k].z));
-            hi = max(hi, max(v[k].y, v[k].w));
+            lo = min(lo, v[k].x);
+            hi = max(hi, v[k].y);
+            nv += (int)v[k].z;
         }
-    }
-    if ((nblk & 1) && threadIdx.x == 0) {
-        lo = min(lo, blk_minmax[2 * (nblk - 1)]);
-        hi = max(hi, blk_minmax[2 * (nblk - 1) + 1]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
         hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+        nv += __shfl_xor(nv, d, 64);
     }
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; s_nv[threadIdx.x >> 6] = nv; }
     __syncthreads();
     if (threadIdx.x == 0) {
         lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
         hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
         DepthCtl c;
+        c.n_vis = s_nv[0] + s_nv[1] + s_nv[2] + s_nv[3];
+        c.pad[0] = c.pad[1] = c.pad[2] = 0;
         if (lo > hi) { c.min_bits = 0xFFFFFFFFu; c.range = 0u; } // nothing visible: every key is 0, one pass (it carries the rectangles)
         else { c.min_bits = lo; c.range = hi - lo + 1u; }
         const int nbits = 32 - __builtin_clz(c.range | 1u);      // keys are 0 .. range
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
     uint32_t kmin = 0u, krange = 0u;
+    bool drop_culled = false;
     if constexpr (DEPTH) {
         const DepthCtl c = *dp.ctl;
         if (dp.pass < c.first) return; // this frame's keys need fewer passes
@@ -243,6 +247,10 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
         in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
         shift = 8 * rel;
         kmin = c.min_bits; krange = c.range;
+        // the first active pass reads all n items and drops the culled ones; the later passes see the n_vis survivors only
+        drop_culled = rel == 0;
+        if (rel > 0) n = c.n_vis;
+        if ((int64_t)blockIdx.x * CHUNK >= n) return;
     }
     __shared__ int h[RADIX];
     if (threadIdx.x < RADIX) h[threadIdx.x] = 0;
@@ -258,7 +266,9 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = base + r * 256 + threadIdx.x;
-        if (k < n) atomicAdd(&h[radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange)], 1);
+        bool take = k < n;
+        if constexpr (DEPTH) take = take && !(drop_culled && (uint32_t)(item[r] >> 32) == 0xFFFFFFFFu);
+        if (take) atomicAdd(&h[radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange)], 1);
     }
     __syncthreads();
     if (threadIdx.x < RADIX) {
@@ -314,6 +324,7 @@ struct ScatterCarry {
     TileRect *rect_sorted;  // [n] in output order
     int32_t *cnt_sorted;    // [n] (x1-x0)*(y1-y0) in output order
     uint32_t *id_sorted;    // [n] Gaussian ids in output order (instead of the 8-byte items: the expansion needs only these)
+    int64_t n_total;        // all Gaussians, culled included (cnt_sorted behind the visible ones is zero-filled)
 };
 
 // FINAL (last pass of the tile partition only): the pass's output IS the sorted list, so instead of the items it writes what
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     int *const s_gbase = s_before;                 // global position of the block's first item of each digit
     __shared__ int s_dcnt[FINAL ? RADIX : 1];      // FINAL: items of each digit in this block
     __shared__ int s_tmp[4];
+    __shared__ int s_valid_n;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * CHUNK;
@@ -367,6 +379,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     // (also by a depth pass that then finds it has nothing to sort)
     for (int z = blockIdx.x * 256 + tid; z < zero_n; z += gridDim.x * 256) zero_acc[z] = 0;
     uint32_t kmin = 0u, krange = 0u;
+    bool drop_culled = false;
+    int64_t n_load = n; // items readable in `in` (the index clamp of the loads)
     if constexpr (DEPTH) {
         const DepthCtl c = *dp.ctl;
         if (dp.pass < c.first) return;
@@ -375,6 +389,16 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         out = reinterpret_cast<ItemT *>(dp.buf[(rel + 1) & 1]);
         shift = 8 * rel;
         kmin = c.min_bits; krange = c.range;
+        // the first active pass reads all n items and drops the culled ones (they have no tiles: nothing downstream wants them);
+        // the later passes move the n_vis survivors.  Everything this pass writes lands in [0, n_vis).
+        drop_culled = rel == 0;
+        if (rel > 0) n = n_load = c.n_vis;
+        if constexpr (CARRY) {
+            // the depth-order scan runs over all N counts: those behind the survivors are zero
+            const int64_t z0 = max((int64_t)c.n_vis, block_base), z1 = min(block_base + (int64_t)CHUNK, carry.n_total);
+            for (int64_t z = z0 + tid; z < z1; z += 256) carry.cnt_sorted[z] = 0;
+        }
+        if (block_base >= n) return;
     }
     __syncthreads();
 
@@ -428,13 +452,14 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     ItemT item[RADIX_ITEMS];
     unsigned long long rc[CARRY ? RADIX_ITEMS : 1]; // raw TileRect bits
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
+    bool valid_bits[RADIX_ITEMS];
     // every load is issued before the ranking starts (the ranking's branches would otherwise pin each load to its own
     // round: RADIX_ITEMS serial memory round trips per wave)
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
-        const ItemT v = in[k < n ? k : n - 1];
-        item[r] = k < n ? v : (ItemT)~(ItemT)0;
+        const ItemT v = in[k < n_load ? k : n_load - 1];
+        item[r] = k < n_load ? v : (ItemT)~(ItemT)0;
     }
     if constexpr (CARRY) { // the random rectangle fetches are in flight during the ranking
         // raw 8-byte loads at a clamped index, no branch: as `valid ? rect[id] : {}` each fetch got its own exec-masked
@@ -442,14 +467,16 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
 #pragma unroll
         for (int r = 0; r < RADIX_ITEMS; ++r) {
             const int64_t k = wave_base + r * 64 + lane;
-            const uint32_t id = k < n ? (uint32_t)item[r] : 0u;
+            const uint32_t id = k < n_load ? (uint32_t)item[r] : 0u;
             rc[r] = reinterpret_cast<const unsigned long long *>(carry.rect)[id];
         }
     }
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int64_t k = wave_base + r * 64 + lane;
-        const bool valid = k < n;
+        bool valid = k < n;
+        if constexpr (DEPTH) valid = valid && !(drop_culled && (uint32_t)(item[r] >> 32) == 0xFFFFFFFFu);
+        valid_bits[r] = valid;
         const int d = radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange);
         // lanes holding the same digit ("match any"): a lane differs from me in bit b where ballot(bit b) XOR (my bit b
         // replicated) is set; OR over the bits, complement.  Written on 32-bit halves with the replicated bit as one signed
@@ -489,6 +516,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         }
         int tot;
         const int inc = block_incl_scan_256(run, s_tmp, &tot);
+        if (tid == 0) s_valid_n = tot; // items of this block that take part (all of its chunk, unless culled ones were dropped)
         // digit base over the whole array = sum of totals of smaller digits; then the items of this digit in earlier blocks:
         // whole super-blocks from the accumulators, the rest of the own super-block from the block histograms
         const int td = own ? s_total[d] : 0;
@@ -509,8 +537,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     // pass 2: reorder in LDS by digit (stable)
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; ++r) {
-        const int64_t k = wave_base + r * 64 + lane;
-        if (k < n) {
+        if (valid_bits[r]) {
             const int d = radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange);
             const int slot = s_dstart[d] + s_wcnt[w][d] + rank[r];
             s_items[slot] = item[r];
@@ -520,7 +547,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     __syncthreads();
 
     // pass 3: contiguous runs out to global memory
-    const int valid_n = (int)((n - block_base) < CHUNK ? (n - block_base) : CHUNK);
+    const int valid_n = s_valid_n;
 #pragma unroll 4
     for (int r = 0; r < RADIX_ITEMS; ++r) {
         const int slot = r * 256 + tid;
@@ -938,7 +965,7 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s)
         return hipGetLastError();
     }
     const int zero_n = (int)gsr_radix_acc_ints(n);
-    const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted};
+    const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted, n};
     for (int pass = 0; pass < 4; ++pass) {
         const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}};
         // pass p accumulates into acc[p & 1] (cleared by preprocess for p = 0) and clears the other one for pass p + 1

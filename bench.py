@@ -262,7 +262,7 @@ def main():
     if use_events:
         # one step in ten (in five for short runs) carries the per-stage HIP events: 14 records cost ~6 % of a C3 step, so the
         # sampled steps are the p90 of step_ms and the wall-clock mean carries ~0.6 % of measurement
-        gsr._lib.stage_timing(True, args.steps, every=10 if args.steps >= 50 else 5 if args.steps >= 10 else 1)
+        gsr._lib.stage_timing(True, args.steps, every=10 if args.steps >= 20 else 5 if args.steps >= 10 else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
