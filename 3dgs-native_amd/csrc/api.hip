@@ -217,12 +217,13 @@ struct CountNote {
     const void *ws;
     int64_t N, D;
     uint64_t stamp;
+    int depth_passes; // how many depth-sort passes the last frame counted in this workspace needed: the next frame's launch guess
 };
 std::mutex g_note_mu;
 std::vector<CountNote> g_notes;
 uint64_t g_note_clock = 0;
 constexpr size_t MAX_NOTES = 256;
-void note_count(const void *ws, int64_t N, int64_t D)
+void note_count(const void *ws, int64_t N, int64_t D, int depth_passes)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -238,7 +239,17 @@ void note_count(const void *ws, int64_t N, int64_t D)
             slot = &*std::min_element(g_notes.begin(), g_notes.end(), [](const CountNote &a, const CountNote &b) { return a.stamp < b.stamp; });
         }
     }
-    *slot = CountNote{dev, ws, N, D, ++g_note_clock};
+    *slot = CountNote{dev, ws, N, D, ++g_note_clock, depth_passes};
+}
+// the depth-sort launch guess for a workspace: what its last frame needed, four if it has none
+int depth_pass_guess(const void *ws)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_note_mu);
+    for (CountNote &c : g_notes)
+        if (c.dev == dev && c.ws == ws) return c.depth_passes >= 1 && c.depth_passes <= 4 ? c.depth_passes : 4;
+    return 4;
 }
 // 1 = matches, 0 = mismatch, -1 = this workspace has no recorded count
 int check_count(const void *ws, int64_t N, int64_t D)
@@ -284,8 +295,8 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.doff = c.take<int32_t>((size_t)N);
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, 256) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
-    w.acc[0] = c.take<int32_t>(gsr_radix_acc_ints(N));
-    w.acc[1] = c.take<int32_t>(gsr_radix_acc_ints(N));
+    w.acc[0] = c.take<int32_t>(2 * gsr_radix_acc_ints(N)); // both passes' accumulators, contiguous: preprocess clears them in one go
+    w.acc[1] = w.acc[0] ? w.acc[0] + gsr_radix_acc_ints(N) : nullptr;
     w.bytes = c.off + 256;
     return w;
 }
@@ -352,23 +363,28 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     // the scan's last wave stores D = point_offsets[N-1] straight into the pinned host word
     // (preprocess left one partial sum per 256 Gaussians in scan_tmp: one launch)
     // (its first wave also turns the per-block depth extremes preprocess left into the depth sort's pass plan, on the device)
+    rb->pinned[1] = 4; // overwritten by the scan's control workgroup with the number of depth passes this frame needs
     HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s, ws.blk_minmax, ws.depth_ctl));
     mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
     // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id order, four 8-bit
     // passes over the high word, ending back in depth_item; the last one also carries each Gaussian's tile rectangle and
     // tile count to its sorted position) and the depth-order offsets (exclusive scan of those counts).
-    {
-        HIP_TRY(gsr_launch_depth_sort(ws, N, s));
-        mark(st, 3, s);
-        if (!gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
-        mark(st, 4, s);
-    }
-    HIP_TRY(hipEventSynchronize(rb->ev)); // D is on the host; the GPU keeps sorting
+    // How many of the four 8-bit passes this frame needs is decided on the device (DepthCtl); the host launches as many as the
+    // previous frame in this workspace needed (its guess; four the first time).  If the guess turns out too low the launched
+    // passes leave the data alone and all four are launched once the readback has said so.
+    const int guess = (gsr_debug_flags & 256) ? 4 : depth_pass_guess(geom_ws);
+    HIP_TRY(gsr_launch_depth_sort(ws, N, s, guess));
+    HIP_TRY(hipEventSynchronize(rb->ev)); // D (and the pass count) are on the host; the GPU keeps sorting
     const int32_t last = *rb->pinned;
+    const int needed = std::min(4, std::max(1, (int)rb->pinned[1]));
+    if (needed > guess && !gsr_small_depth_path(N)) HIP_TRY(gsr_launch_depth_sort(ws, N, s, 4));
+    mark(st, 3, s);
+    if (!gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
+    mark(st, 4, s);
     *num_rendered = (int64_t)last;
     if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
-    note_count(geom_ws, N, (int64_t)last);
+    note_count(geom_ws, N, (int64_t)last, needed);
     return GSR_OK;
 }
 

@@ -62,7 +62,7 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
                            int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */,
                            bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s,
                            const uint32_t *blk_minmax = nullptr, void *depth_ctl = nullptr /* mode 0: also derive the depth sort's DepthCtl */);
-hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s);
+hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes = 4 /* the last `launch_passes` of the four */);
 #define GSR_SMALL_SORT_N 8192          // up to this many Gaussians one workgroup sorts, carries and scans (scan_sort.hip)
 bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes the depth-order offsets (no separate scan)
 

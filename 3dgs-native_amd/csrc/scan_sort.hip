@@ -17,6 +17,8 @@
 // over 8-byte sc1 status words was built and measured in round 1: bit-identical output but 1.4-2.1x
 // SLOWER on MI355X -- depth sort 0.196 vs 0.093 ms, tile sort 0.187 vs 0.131 ms at C3 -- because every
 // look-back hop is a ~1-3 us memory-side round trip and all chunks run in lockstep; see DESIGN.md.)
+#include <algorithm>
+
 #include "gsr_internal.h"
 
 namespace {
@@ -101,7 +103,8 @@ struct DepthCtl {
 
 // Run by ONE wave of the id-order scan (which follows preprocess in the stream and precedes the depth passes): preprocess left
 // the smallest and largest visible depth bits of every 256-Gaussian block (0xFFFFFFFF / 0 for a block without a visible one).
-__device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass)
+__device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass,
+                                                      int32_t *host_words)
 {
     // one 256-thread workgroup; 16-byte loads (two blocks each), all of a thread's loads in flight before anything is combined:
     // 8 bytes x N / 256 (31 KB at a million Gaussians) in one or two memory round trips
@@ -144,6 +147,7 @@ __device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict
         c.npass = force_npass > 0 ? force_npass : max(1, (nbits + 7) / 8); // forced (tests: GSR_DEBUG bit 8 = always four): same order
         c.first = 4 - c.npass;
         *ctl = c;
+        if (host_words) host_words[1] = c.npass; // beside D in the pinned readback words: the host's launch guess for the next frame
     }
 }
 
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t base = wid * SCAN_WAVE_ITEMS;
     if (ctl && blockIdx.x == gridDim.x - 1) { // one extra workgroup, launched for this alone: off the scan's critical path
-        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass);
+        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass, total_out);
         return;
     }
     if (base >= n) return;
@@ -224,6 +228,9 @@ struct DepthPass {
     const DepthCtl *ctl;
     int pass;            // 0 .. 3
     uint64_t *buf[2];    // ping-pong buffers; the first ACTIVE pass reads buf[0]
+    int launched_first;  // the host launched the passes launched_first .. 3 only (its guess from the previous frame): if this
+                         // frame needs an earlier one (ctl->first < launched_first), every launched pass leaves the data alone
+                         // and the host, told by the readback, launches all four
 };
 template <bool DEPTH, int BITS, typename ItemT>
 __device__ __forceinline__ int radix_digit(ItemT item, int shift, uint32_t kmin, uint32_t krange)
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     bool drop_culled = false;
     if constexpr (DEPTH) {
         const DepthCtl c = *dp.ctl;
-        if (dp.pass < c.first) return; // this frame's keys need fewer passes
+        if (dp.pass < c.first || c.first < dp.launched_first) return; // this frame's keys need fewer passes / more than were launched
         const int rel = dp.pass - c.first;
         in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
         shift = 8 * rel;
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     int64_t n_load = n; // items readable in `in` (the index clamp of the loads)
     if constexpr (DEPTH) {
         const DepthCtl c = *dp.ctl;
-        if (dp.pass < c.first) return;
+        if (dp.pass < c.first || c.first < dp.launched_first) return;
         const int rel = dp.pass - c.first;
         in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
         out = reinterpret_cast<ItemT *>(dp.buf[(rel + 1) & 1]);
@@ -956,9 +963,10 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
 // and each Gaussian's tile rectangle and tile count carried to its sorted position.
 bool gsr_small_depth_path(int64_t n) { return n <= GSR_SMALL_SORT_N && !(gsr_debug_flags & 1024); } // GSR_DEBUG bit 10: never (tests)
 
-hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s)
+hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes)
 {
     if (n <= 0) return hipSuccess;
+    launch_passes = std::min(4, std::max(1, launch_passes));
     if (gsr_small_depth_path(n)) { // sorts, carries AND scans: the caller skips the depth-order scan
         hipLaunchKernelGGL(depth_sort_small_kernel, dim3(1), dim3(1024), 0, s, ws.depth_item, (int)n, ws.rect, ws.id_sorted, ws.rect_sorted,
                            ws.cnt_sorted, ws.doff);
@@ -966,8 +974,8 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s)
     }
     const int zero_n = (int)gsr_radix_acc_ints(n);
     const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted, n};
-    for (int pass = 0; pass < 4; ++pass) {
-        const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}};
+    for (int pass = 4 - launch_passes; pass < 4; ++pass) {
+        const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}, 4 - launch_passes};
         // pass p accumulates into acc[p & 1] (cleared by preprocess for p = 0) and clears the other one for pass p + 1
         if (pass < 3)
             radix_pass_launch<8, uint64_t, false, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, ws.acc[(pass + 1) & 1], zero_n,

@@ -166,6 +166,27 @@ def test_depth_ranges_and_the_device_side_pass_plan(oracle, cameras, scenes, nea
     assert (d > 0).sum() > n // 2 and abs(float(d[d > 0].min()) - near) < 0.2 * near + 0.5 and int(parity.to_np(got[2]["point_list"]).size) > n
 
 
+def test_depth_pass_guess_misses_and_overshoots(oracle, cameras, scenes):
+    """The host launches as many depth-sort passes as the PREVIOUS frame in the same workspace needed; the device decides how
+    many this frame needs.  A sequence of frames through one workspace whose need goes 1 -> 4 (guess too low: the launched
+    passes must leave the data alone and the full sort is launched after the readback) -> 3 -> 1 (guess too high: the extra
+    launches exit) -> 4 must give the exact list every time.  N is above the single-workgroup small-scene path."""
+    n = 9000
+    cam = cameras.nerf_camera(np.eye(4).tolist(), 208, 144, 0.6911112)
+    for k, (near, far) in enumerate([(3.0, 3.0), (0.25, 90.0), (2.0, 7.9), (5.0, 5.0), (0.5, 200.0), (0.5, 200.0)]):
+        sc = scenes.synthetic_scene(n, 0.02, 0.5, 900 + k)
+        rng = np.random.default_rng(k)
+        depth = rng.uniform(near, far, n).astype(np.float32)
+        depth[::5] = -depth[::5]
+        sc["means"][:, 2] = -depth
+        sc["means"][:, :2] = (rng.uniform(-0.4, 0.4, (n, 2)) * np.abs(depth)[:, None]).astype(np.float32)
+        sc["scales"] *= np.abs(depth)[:, None] / 3.0
+        kw = render_kwargs(sc, cam, width=208, height=144)
+        _, got, ref = _both(oracle, kw)
+        parity.compare_forward(got, ref)
+        assert int(parity.to_np(got[2]["point_list"]).size) > n
+
+
 def test_huge_gaussian_covers_all_tiles(oracle, cameras, scenes):
     sc = scenes.synthetic_scene(50, 0.05, 0.5, 33)
     sc["scales"][0] = 5.0
