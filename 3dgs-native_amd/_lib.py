@@ -97,7 +97,7 @@ EXPORTS = {
     "gsr_stage_times": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
-STAGES = ["preprocess", "scan", "depth_sort", "depth_scan", "host_gap", "expand", "tile_sort", "ranges", "blend_fwd",
+STAGES = ["preprocess", "scan", "depth_sort", "host_gap", "depth_scan", "expand", "tile_sort", "ranges", "blend_fwd",
           "bwd_prep", "blend_bwd", "geom_bwd"]
 
 _lib = None

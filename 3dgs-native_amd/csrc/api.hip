@@ -297,6 +297,7 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
     w.acc[0] = c.take<int32_t>(2 * gsr_radix_acc_ints(N)); // both passes' accumulators, contiguous: preprocess clears them in one go
     w.acc[1] = w.acc[0] ? w.acc[0] + gsr_radix_acc_ints(N) : nullptr;
+    w.sum4096 = c.take<int32_t>((size_t)gsr_div_up(N, 4096) + 4);
     w.bytes = c.off + 256;
     return w;
 }
@@ -380,8 +381,9 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     const int needed = std::min(4, std::max(1, (int)rb->pinned[1]));
     if (needed > guess && !gsr_small_depth_path(N)) HIP_TRY(gsr_launch_depth_sort(ws, N, s, 4));
     mark(st, 3, s);
-    if (!gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
-    mark(st, 4, s);
+    // (the depth-order offsets are made by gsr_forward_render, next to their one reader -- the expansion; the alternative path of
+    // GSR_DEBUG bit 9 scans them here, into ws.doff)
+    if ((gsr_debug_flags & 512) && !gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(ws.cnt_sorted, nullptr, ws.doff, ws.scan_tmp, N, 2, nullptr, false, s));
     *num_rendered = (int64_t)last;
     if (last < 0 || (int64_t)last > GSR_MAX_RENDERED) return GSR_E_OVERFLOW;
     note_count(geom_ws, N, (int64_t)last, needed);
@@ -424,7 +426,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
 
     const int st = t_fwd_record;
     t_fwd_record = -1;
-    mark(st, 5, s);
+    mark(st, 4, s); // (stage 3 -> 4: the host between the two calls -- the wait for D, the caller's allocations)
     // 3. expansion of the depth-sorted Gaussians (gsr_forward_count) to (tile << id_shift | id) items.  When the tile
     //    bits and the id bits fit one 32-bit word (800x800 with 1M Gaussians: 12 + 20) the items are uint32, which
     //    halves the traffic of the expansion, both partition passes and the range scan.
@@ -433,25 +435,38 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     while ((1LL << id_bits) < N) ++id_bits;
     const bool narrow = tb + id_bits <= 32 && !(gsr_debug_flags & 32); // GSR_DEBUG bit 5: 64-bit tile items at any size (tests)
     const int id_shift = narrow ? id_bits : 32, item_bytes = narrow ? 4 : 8;
+    // the stable partition by tile id below: ceil(tb/8) passes over the tile-id bits, split as evenly as possible (12 bits -> 6+6, 13 -> 7+6)
+    const int npass = (tb + 7) / 8;
+    auto pass_bits = [&](int pass, int shift) { return std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass)); };
     // the block order (forward -> backward scratch): header cleared here; filed by the blend below unless the image is large
     int32_t *order = binning->block_masks ? binning->block_order : nullptr;
     const bool file_order = order && tiles <= GSR_BO_MAX_TILES;
-    HIP_TRY(gsr_launch_expand(gw.id_sorted, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
-                              (int)gsr_radix_acc_ints(D), order, order ? GSR_BO_HEADER : 0, file_order ? 1 : 0, s));
+    const bool by_gaussian = (gsr_debug_flags & 512) != 0; // GSR_DEBUG bit 9: the expansion by Gaussian + the first pass's own histogram kernel (tests, A/B)
+    if (by_gaussian) {
+        mark(st, 5, s);
+        HIP_TRY(gsr_launch_expand(gw.id_sorted, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
+                                  (int)gsr_radix_acc_ints(D), order, order ? GSR_BO_HEADER : 0, file_order ? 1 : 0, s));
+    } else {
+        // one offset per 256 depth-sorted Gaussians (stage "depth_scan"), then one workgroup per radix block of the item array,
+        // which also leaves the first partition pass's block histograms
+        HIP_TRY(gsr_launch_depth_block_offsets(gw, N, binning->ranges, 2 * tiles, bw.acc[0], (int)gsr_radix_acc_ints(D), order, order ? GSR_BO_HEADER : 0,
+                                               file_order ? 1 : 0, s));
+        mark(st, 5, s);
+        HIP_TRY(gsr_launch_expand_blocks(gw, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, pass_bits(0, 0), bw.hist, bw.acc[0], s));
+    }
     mark(st, 6, s);
-    // 4. stable partition by tile id: ceil(tb/8) passes over the tile-id bits, split as evenly as possible
-    //    (12 bits -> 6+6, 13 -> 7+6)
+    // 4. stable partition by tile id
     void *tsrc = bw.tile_a, *tdst = bw.tile_b;
-    const int npass = (tb + 7) / 8;
     for (int pass = 0, shift = 0; pass < npass; ++pass) {
-        const int bits = std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass));
+        const int bits = pass_bits(pass, shift);
+        const bool hist_ready = pass == 0 && !by_gaussian;
         if (pass + 1 < npass) {
-            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, bw.acc[(pass + 1) & 1], s));
+            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, bw.acc[(pass + 1) & 1], s, hist_ready));
         } else {
             // 5. the last pass writes point_list and the tile ranges itself (reference forward.py:806-824, :561-586) instead of
             //    sorted items that a further kernel would re-read
             HIP_TRY(gsr_launch_radix_final_pass(tsrc, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, id_shift, binning->point_list,
-                                                binning->ranges, bw.edge, s));
+                                                binning->ranges, bw.edge, s, hist_ready));
         }
         shift += bits;
         void *t = tsrc; tsrc = tdst; tdst = t;

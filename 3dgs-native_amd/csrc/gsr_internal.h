@@ -48,6 +48,7 @@ struct GeomWs {
     int32_t *scan_tmp;    // [N / 256 + 4] partial sums for the scans (preprocess writes one per 256 Gaussians)
     int32_t *hist;        // [nb(N)][256] radix block histograms
     int32_t *acc[2];      // [gsr_radix_acc_ints(N)] each: digit + super-block totals of a pass; consecutive passes alternate
+    int32_t *sum4096;     // [N / 4096 + 1] tile pairs per 4096 depth-sorted Gaussians (depth_block_offsets_kernel; scan_tmp holds the 256-level)
     size_t bytes;
 };
 GeomWs gsr_carve_geom(void *base, int64_t N);
@@ -67,7 +68,9 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int
 bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes the depth-order offsets (no separate scan)
 
 // One stable LSD radix pass by the `bits`-wide (4..8) digit at `shift`; items are uint64 (item_bytes 8) or uint32 (4).
+#ifndef GSR_RADIX_CHUNK
 #define GSR_RADIX_CHUNK 4096
+#endif
 #define GSR_RADIX_SMALL_CHUNK 1024      // chunk used when n <= GSR_RADIX_SMALL_N (more, smaller blocks)
 #define GSR_RADIX_SMALL_N (4 << 20)
 static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_N ? (n + GSR_RADIX_SMALL_CHUNK - 1) / GSR_RADIX_SMALL_CHUNK : (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
@@ -87,18 +90,27 @@ static inline size_t gsr_radix_acc_ints(int64_t n)
     return 256 * (size_t)(3 + nb / sb);
 }
 hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[nb][radix]*/, int32_t *acc /* gsr_radix_acc_ints(n), zero */,
-                                 int64_t n, int shift, int bits, int item_bytes, int32_t *zero_acc /* next pass's, or NULL */, hipStream_t s);
+                                 int64_t n, int shift, int bits, int item_bytes, int32_t *zero_acc /* next pass's, or NULL */, hipStream_t s,
+                                 bool hist_ready = false /* hist and acc were filled by gsr_launch_expand_blocks */);
 
 // Last pass of the tile partition: writes point_list and ranges instead of the sorted items (scan_sort.hip, ScatterFinal).
 // `edge`: 3 * 256 * (gsr_radix_blocks(n) + 1) int32 of scratch.
 hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
-                                       int id_shift, int32_t *point_list, int32_t *ranges /* pre-zeroed */, int32_t *edge, hipStream_t s);
+                                       int id_shift, int32_t *point_list, int32_t *ranges /* pre-zeroed */, int32_t *edge, hipStream_t s,
+                                       bool hist_ready = false);
 
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
 hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, const TileRect *rect, void *tile_items,
                              int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int32_t *ranges, int ranges_n,
                              int32_t *zero_acc, int zero_n /* accumulators of the first partition pass, cleared here */,
                              int32_t *zero_b, int zero_b_n /* the block-order header, or NULL */, int bo_flag /* its `filed` flag */, hipStream_t s);
+// The product path of the expansion (scan_sort.hip): one prefix per 256 depth-sorted Gaussians (into ws.scan_tmp; also clears the
+// ranges, the first partition pass's accumulators and the block-order header), then one workgroup per radix block of the output,
+// which also leaves the first partition pass's histograms (launch that pass with hist_ready).
+hipError_t gsr_launch_depth_block_offsets(const GeomWs &ws, int64_t n, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n, int32_t *zero_b,
+                                          int zero_b_n, int bo_flag, hipStream_t s);
+hipError_t gsr_launch_expand_blocks(const GeomWs &ws, void *tile_items, int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int bits0,
+                                    int32_t *hist, int32_t *acc, hipStream_t s);
 // ---- block order (GsrBinning.block_order): the backward blend's 8x4-pixel blocks, heaviest first ---------------------------
 // The backward's waves live 40-90 us of a 165-us kernel, so what starts last decides when the kernel ends.  How many list
 // entries the backward's compaction will keep for a block (mask hits up to the block's last contributor) is the one cheap
@@ -156,7 +168,8 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
 hipError_t gsr_launch_view_payload(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc, float *payload, hipStream_t s);
 // GSR_DEBUG (environment, read once): bit 5 forces 64-bit tile items, bit 6 the large-n radix chunks, bit 7 the scanned
 // super-block rows of many-block radix passes (radix_superscan_kernel), bit 8 all four depth-sort passes whatever the depth
-// range, bit 9 the 8-Gaussians-per-wave expansion whatever D / N; bit 10 switches the
+// range, bit 9 the expansion by Gaussian (a wave per 64 or 8 of them, from a device-wide scan of the depth-order offsets, followed
+// by the first partition pass's own histogram kernel) instead of the expansion by output block; bit 10 switches the
 // one-workgroup depth stage of small scenes OFF (so small test scenes also run the multi-kernel chain) -- same results by
 // other code paths (tests/test_gpu_alt_paths.py).  Bits 0-3 are timing ablations that give WRONG results (skip the atomics,
 // one pixel per bucket, no SH fetch, no stores); they exist only in the separate ablation build (`make ablate` ->

@@ -724,6 +724,169 @@ __global__ __launch_bounds__(256) void expand_kernel(const uint32_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// expansion, by OUTPUT block (the product path; the kernel above is the alternative path of GSR_DEBUG bit 9)
+// ---------------------------------------------------------------------------------------------
+// The depth-order offsets are an exclusive scan of the sorted tile counts.  As a device-wide scan that was two launches
+// (12 us at C3 for 4 MB) whose output, 4 bytes per Gaussian, the expansion read straight back.  Now one small streaming kernel
+// leaves two levels of partial sums and the expansion does the rest itself: per workgroup of this kernel (4096 depth-sorted
+// Gaussians) the total (sum4096), and per 256 Gaussians the exclusive prefix INSIDE its 4096 (pre256).  (A single-kernel
+// version in which the last workgroup to finish turned the sums into global prefixes was tried first: sums written by one
+// XCD and read by another need device-scope release/acquire, i.e. whole-L2 write-backs -- 72 us -- or atomics around the
+// caches -- 13 us at C3, 39 us at C5; this kernel is 5 us.)
+// It also clears what the expansion's workgroups can no longer clear for the kernel behind them, because they now ADD to
+// it: the first partition pass's accumulators -- and the tile ranges and the block-order header, as the expansion did.
+__global__ __launch_bounds__(1024) void depth_block_offsets_kernel(const int32_t *__restrict__ cnt_sorted, int64_t n, int32_t *__restrict__ pre256,
+                                                                   int nsum, int32_t *__restrict__ sum4096, int32_t *__restrict__ ranges, int ranges_n,
+                                                                   int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ zero_b, int zero_b_n,
+                                                                   int bo_flag)
+{
+    for (int64_t z = (int64_t)blockIdx.x * 1024 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 1024) zero_acc[z] = 0;
+    for (int64_t z = (int64_t)blockIdx.x * 1024 + threadIdx.x; z < zero_b_n; z += (int64_t)gridDim.x * 1024) zero_b[z] = (z == GSR_BO_FLAG) ? bo_flag : 0;
+    for (int64_t z = (int64_t)blockIdx.x * 1024 + threadIdx.x; z < ranges_n; z += (int64_t)gridDim.x * 1024) ranges[z] = 0;
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int blk = (int)blockIdx.x * 16 + w;
+    int v = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t k = (int64_t)blk * 256 + r * 64 + lane;
+        if (k < n) v += cnt_sorted[k];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane == 0) s_wsum[w] = v;
+    __syncthreads();
+    if (tid < 16) {
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = s_wsum[k];
+            if (k < tid) before += t;
+            tot += t;
+        }
+        if ((int)blockIdx.x * 16 + tid < nsum) pre256[blockIdx.x * 16 + tid] = before;
+        if (tid == 0) sum4096[blockIdx.x] = tot;
+    }
+}
+
+// One workgroup per radix block of the OUTPUT: workgroup b writes the items [b * chunk, (b + 1) * chunk) -- whatever Gaussians
+// they belong to -- so (1) the work per workgroup is the same whether a Gaussian covers four tiles or four thousand (the
+// wave-per-64-Gaussians kernel above needed a second shape for the trainer's initial point set), and (2) the workgroup has seen
+// exactly one block of the first partition pass and leaves that pass's histogram row and super-block sums behind: the pass's
+// histogram kernel, which re-read all D items, is not launched.  It finds the 256-Gaussian block holding its first item by a
+// two-level search of pre256 (two dependent loads), then walks blocks of 256 Gaussians: rectangle -> count -> offsets by a
+// block scan on top of pre256[B], and every thread places items by an 8-step search of the 256 offsets in LDS.
+template <typename ItemT>
+__global__ __launch_bounds__(256) void expand_blocks_kernel(const uint32_t *__restrict__ id_sorted, const int32_t *__restrict__ cnt_sorted,
+                                                            const int32_t *__restrict__ pre256, const int32_t *__restrict__ sum4096, int nsum,
+                                                            const TileRect *__restrict__ rect, ItemT *__restrict__ tile_items, int64_t n, int grid_x,
+                                                            int64_t D, int id_shift, int chunk, int digit_mask, int32_t *__restrict__ hist,
+                                                            int32_t *__restrict__ acc, int sb)
+{
+    __shared__ int s_off[256];
+    __shared__ TileRect s_rect[256];
+    __shared__ uint32_t s_gid[256];
+    __shared__ float s_inv[256]; // 1 / (rectangle width in tiles)
+    __shared__ int s_h[256];
+    __shared__ int s_tmp[4];
+    const int tid = threadIdx.x;
+    const int lo = (int)((int64_t)blockIdx.x * chunk), hi = (int)min(D, (int64_t)lo + chunk); // never past the caller's D
+    s_h[tid] = 0;
+    // The 256-Gaussian block B0 holding the owner of item lo (the last B whose offset is <= lo: empty Gaussians share their
+    // successor's offset) and that block's offset, from the two levels depth_block_offsets_kernel left: scan the 4096-totals
+    // (every workgroup does; there are N / 4096 of them), pick the 4096 S, then pick among its sixteen 256-prefixes.
+    __shared__ int s_pick[2];
+    int B0, base0;
+    {
+        const int nsuper = (nsum + 15) >> 4, per = (nsuper + 255) / 256;
+        const int q0 = min(nsuper, tid * per), q1 = min(nsuper, q0 + per);
+        int strip = 0;
+        for (int q = q0; q < q1; ++q) strip += sum4096[q];
+        int tot;
+        const int excl = block_incl_scan_256(strip, s_tmp, &tot) - strip; // offset of 4096-block q0
+        int cnt = 0, run = excl, at = excl; // how many of my 4096-blocks start at or before lo, and the offset of the last of them
+        for (int q = q0; q < q1; ++q) {
+            if (run <= lo) { ++cnt; at = run; }
+            run += sum4096[q];
+        }
+        int csum;
+        const int cincl = block_incl_scan_256(cnt, s_tmp, &csum);
+        // the 4096-blocks starting at or before lo are a prefix of all of them: the last one, S = csum - 1, is in the strip of
+        // the one thread whose inclusive count reaches csum with cnt > 0
+        if (cnt > 0 && cincl == csum) { s_pick[0] = csum - 1; s_pick[1] = at; }
+        __syncthreads();
+        const int S = s_pick[0], sbase = s_pick[1];
+        const int b = S * 16 + tid;
+        const int off = (tid < 16 && b < nsum) ? sbase + pre256[b] : 0;
+        const int t2 = __syncthreads_count(tid < 16 && b < nsum && off <= lo); // >= 1: the 4096's first block starts at sbase <= lo
+        if (tid == t2 - 1) s_pick[1] = off;
+        B0 = S * 16 + t2 - 1;
+        __syncthreads();
+        base0 = s_pick[1];
+    }
+    int base = base0;
+    // (software pipeline: the next block's rectangle and id are requested before this block's items are placed)
+    // (the count comes from cnt_sorted, the array the two levels of sums were made from -- it is zero behind the visible
+    // Gaussians, where rect_sorted and id_sorted hold whatever an earlier frame left: the sort drops the culled ones)
+    TileRect rc = {0, 0, 0, 0};
+    uint32_t id = 0;
+    int cnt = 0;
+    {
+        const int64_t k = (int64_t)B0 * 256 + tid;
+        if (k < n) { rc = rect[k]; id = id_sorted[k]; cnt = cnt_sorted[k]; } // in depth order (carried by the last sort pass)
+    }
+    for (int B = B0; B < nsum; ++B) {
+        const int wd = cnt > 0 ? (int)rc.x1 - (int)rc.x0 : 0;
+        int tot;
+        const int inc = block_incl_scan_256(cnt, s_tmp, &tot); // (its barriers also fence the previous block's readers of the arrays below)
+        s_off[tid] = base + inc - cnt;
+        s_rect[tid] = rc;
+        s_gid[tid] = id;
+        s_inv[tid] = wd > 0 ? 1.0f / (float)wd : 0.0f;
+        const int end = base + tot;
+        int next_cnt = 0;
+        if (end < hi && B + 1 < nsum) {
+            const int64_t k = (int64_t)(B + 1) * 256 + tid;
+            rc = TileRect{0, 0, 0, 0};
+            id = 0;
+            next_cnt = 0;
+            if (k < n) { rc = rect[k]; id = id_sorted[k]; next_cnt = cnt_sorted[k]; }
+        }
+        __syncthreads();
+        const int j0 = max(lo, base), j1 = min(hi, end);
+        for (int j = (j0 & ~255) + tid; j < j1; j += 256) { // 256 consecutive items per step, aligned: coalesced stores
+            if (j < j0) continue;
+            int p = 0; // last entry with off <= j
+#pragma unroll
+            for (int step = 128; step >= 1; step >>= 1)
+                if (s_off[p + step] <= j) p += step;
+            const TileRect r = s_rect[p];
+            const int t = j - s_off[p];
+            const int rw = (int)r.x1 - (int)r.x0;
+            // row-major walk: y = t / rw, x = t % rw (reference forward.py:546-548); t < 2^24, so the quotient comes from one float
+            // multiply by the Gaussian's 1 / rw and a +-1 correction
+            int y = (int)((float)t * s_inv[p]);
+            int x = t - y * rw;
+            if (x < 0) { --y; x += rw; }
+            else if (x >= rw) { ++y; x -= rw; }
+            const uint32_t tile = (uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x);
+            tile_items[j] = (ItemT)(((ItemT)tile << id_shift) | (ItemT)s_gid[p]);
+            atomicAdd(&s_h[tile & (uint32_t)digit_mask], 1);
+        }
+        if (end >= hi) break;
+        base = end; // the next block starts where this one ends
+        cnt = next_cnt;
+    }
+    __syncthreads();
+    // what radix_hist_kernel would have left for this block of the first partition pass
+    if (tid <= digit_mask) {
+        const int c = s_h[tid];
+        hist[(size_t)blockIdx.x * (digit_mask + 1) + tid] = c;
+        if (c) atomicAdd(&acc[256 + ((int)blockIdx.x / sb) * 256 + tid], c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // small scenes: the whole depth stage in ONE workgroup
 // ---------------------------------------------------------------------------------------------
 // Up to GSR_SMALL_SORT_N Gaussians (the reference trainer starts with 5 000): ten launches of 5 us each -- four histogram /
@@ -894,17 +1057,22 @@ static PassGeom pass_geom(int64_t n)
 
 template <int BITS, typename ItemT, bool CARRY, bool FINAL, bool DEPTH = false>
 static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int32_t *zero_acc, int zero_n,
-                              const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s, const DepthPass &dp = DepthPass{})
+                              const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s, const DepthPass &dp = DepthPass{}, bool hist_ready = false)
 {
     const PassGeom g = pass_geom(n);
     // (a skipped depth pass leaves its accumulator rows zero: the super-block scan of a many-block pass then scans zeros)
-    if (g.small) {
+    // hist_ready: the kernel that produced `in` left this pass's block histograms and super-block sums (expand_blocks_kernel)
+    if (hist_ready) {
+    } else if (g.small) {
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
+    } else {
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
+    }
+    if (g.small) {
         if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
                            n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
         if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
                            shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
@@ -916,15 +1084,16 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
 
 template <typename ItemT, bool FINAL>
 static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int32_t *zero_acc,
-                                 int zero_n, const ScatterFinal &fin, hipStream_t s)
+                                 int zero_n, const ScatterFinal &fin, hipStream_t s, bool hist_ready)
 {
     const ScatterCarry nc{};
+    const DepthPass nd{};
     switch (bits) {
-    case 4: radix_pass_launch<4, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
-    case 5: radix_pass_launch<5, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
-    case 6: radix_pass_launch<6, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
-    case 7: radix_pass_launch<7, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
-    case 8: radix_pass_launch<8, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s); break;
+    case 4: radix_pass_launch<4, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+    case 5: radix_pass_launch<5, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+    case 6: radix_pass_launch<6, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+    case 7: radix_pass_launch<7, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+    case 8: radix_pass_launch<8, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -936,25 +1105,25 @@ static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int
 // `acc`: this pass's accumulators (gsr_radix_acc_ints(n) ints, zero when the pass's first kernel runs); `zero_acc`: the
 // accumulators of the NEXT pass over the same n, cleared by this pass's scatter (or NULL).
 hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
-                                 int32_t *zero_acc, hipStream_t s)
+                                 int32_t *zero_acc, hipStream_t s, bool hist_ready)
 {
     if (n <= 0) return hipSuccess;
     const int zero_n = zero_acc ? (int)gsr_radix_acc_ints(n) : 0;
     if (item_bytes == 4)
-        return radix_pass_any<uint32_t, false>((const uint32_t *)in, (uint32_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s);
-    return radix_pass_any<uint64_t, false>((const uint64_t *)in, (uint64_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s);
+        return radix_pass_any<uint32_t, false>((const uint32_t *)in, (uint32_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s, hist_ready);
+    return radix_pass_any<uint64_t, false>((const uint64_t *)in, (uint64_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s, hist_ready);
 }
 
 // The LAST pass of the tile partition: histogram, then a scatter that writes point_list and the in-sight range boundaries
 // directly (ScatterFinal), and the edge fix-up.  `edge` holds 3 * (1 << bits) * nb int32 (gsr_radix_blocks(n) = nb).
 hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
-                                       int id_shift, int32_t *point_list, int32_t *ranges, int32_t *edge, hipStream_t s)
+                                       int id_shift, int32_t *point_list, int32_t *ranges, int32_t *edge, hipStream_t s, bool hist_ready)
 {
     if (n <= 0) return hipSuccess;
     const size_t per = ((size_t)1 << bits) * (size_t)gsr_radix_blocks(n);
     const ScatterFinal fin{point_list, ranges, edge, edge + per, edge + 2 * per, acc, id_shift};
-    if (item_bytes == 4) return radix_pass_any<uint32_t, true>((const uint32_t *)in, (uint32_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s);
-    return radix_pass_any<uint64_t, true>((const uint64_t *)in, (uint64_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s);
+    if (item_bytes == 4) return radix_pass_any<uint32_t, true>((const uint32_t *)in, (uint32_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s, hist_ready);
+    return radix_pass_any<uint64_t, true>((const uint64_t *)in, (uint64_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s, hist_ready);
 }
 
 // The depth sort: Gaussians by depth bits, stable from id order.  Four 8-bit passes over the 64-bit (depth bits << 32 | id) items
@@ -991,12 +1160,39 @@ hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, con
                              int32_t *zero_b, int zero_b_n, int bo_flag, hipStream_t s)
 {
     if (n <= 0 || D <= 0) return hipSuccess;
-    const bool few = D / n >= 32 || (gsr_debug_flags & 512); // GSR_DEBUG bit 9: the 8-per-wave expansion at any size (tests)
+    const bool few = D / n >= 32;
 #define EXPAND(T, G)                                                                                                          \
     hipLaunchKernelGGL((expand_kernel<T, G>), dim3((unsigned)gsr_div_up(n, 4 * (G))), dim3(256), 0, s, id_sorted, doff, rect, (T *)tile_items, n, grid_x, D, \
                        id_shift, ranges, ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag)
     if (item_bytes == 4) { if (few) EXPAND(uint32_t, 8); else EXPAND(uint32_t, 64); }
     else { if (few) EXPAND(uint64_t, 8); else EXPAND(uint64_t, 64); }
 #undef EXPAND
+    return hipGetLastError();
+}
+
+// The product path of the expansion: gsr_launch_depth_block_offsets, then gsr_launch_expand_blocks (see the kernels).
+hipError_t gsr_launch_depth_block_offsets(const GeomWs &ws, int64_t n, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n, int32_t *zero_b,
+                                          int zero_b_n, int bo_flag, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const int nsum = (int)gsr_div_up(n, 256);
+    hipLaunchKernelGGL(depth_block_offsets_kernel, dim3((unsigned)gsr_div_up(nsum, 16)), dim3(1024), 0, s, ws.cnt_sorted, n, ws.scan_tmp, nsum, ws.sum4096, ranges,
+                       ranges_n, zero_acc, zero_n, zero_b, zero_b_n, bo_flag);
+    return hipGetLastError();
+}
+// `bits0`: the digit width of the first partition pass over the D items (its digit = the low bits0 bits of the tile id); `hist`,
+// `acc`: that pass's block histograms and (zeroed) accumulators, which this kernel fills -- launch the pass with hist_ready.
+hipError_t gsr_launch_expand_blocks(const GeomWs &ws, void *tile_items, int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int bits0,
+                                    int32_t *hist, int32_t *acc, hipStream_t s)
+{
+    if (n <= 0 || D <= 0) return hipSuccess;
+    const PassGeom g = pass_geom(D);
+    const int chunk = g.small ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK, nsum = (int)gsr_div_up(n, 256);
+    if (item_bytes == 4)
+        hipLaunchKernelGGL(expand_blocks_kernel<uint32_t>, dim3(g.nb), dim3(256), 0, s, ws.id_sorted, ws.cnt_sorted, ws.scan_tmp, ws.sum4096, nsum, ws.rect_sorted, (uint32_t *)tile_items, n,
+                           grid_x, D, id_shift, chunk, (1 << bits0) - 1, hist, acc, g.sb);
+    else
+        hipLaunchKernelGGL(expand_blocks_kernel<uint64_t>, dim3(g.nb), dim3(256), 0, s, ws.id_sorted, ws.cnt_sorted, ws.scan_tmp, ws.sum4096, nsum, ws.rect_sorted, (uint64_t *)tile_items, n,
+                           grid_x, D, id_shift, chunk, (1 << bits0) - 1, hist, acc, g.sb);
     return hipGetLastError();
 }

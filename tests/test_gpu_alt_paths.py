@@ -2,7 +2,9 @@
 4096-item radix chunks of the depth sort (N > 4 M), the scanned super-block rows of radix passes over more than 2048 blocks
 (D > 8.4 M) -- only run at sizes the oracle cannot replay.  GSR_DEBUG bits 5, 6 and 7
 force them at any size, so the oracle comparison covers them too; bit 8 makes the depth sort run all four of its 8-bit passes
-whatever the frame's depth range (by default the device decides: three for a scene within two octaves of depth).  The library reads GSR_DEBUG once, hence a subprocess."""
+whatever the frame's depth range (by default the device decides: three for a scene within two octaves of depth); bit 9 the
+expansion by Gaussian with its device-wide offset scan and separate first histogram (the product path expands by output block);
+bit 10 the multi-kernel depth stage for small scenes too.  The library reads GSR_DEBUG once, hence a subprocess."""
 import os
 import subprocess
 import sys
