@@ -187,6 +187,36 @@ def test_depth_pass_guess_misses_and_overshoots(oracle, cameras, scenes):
         assert int(parity.to_np(got[2]["point_list"]).size) > n
 
 
+@pytest.mark.parametrize("case", ["specks_and_giants", "giants_only", "mostly_culled"])
+def test_expansion_by_output_block(oracle, cameras, scenes, case):
+    """The expansion hands every workgroup one radix block of the OUTPUT (1024 items at these sizes) and lets it find the
+    Gaussians that own those items: thousands of one-tile specks per block (many 256-Gaussian batches per workgroup), giants
+    that cover every tile (one Gaussian spread over many workgroups; blocks that begin and end inside one Gaussian; D an exact
+    multiple of the block when all of them cover all 256 tiles), and a scene whose Gaussians are mostly behind the camera
+    (the sorted arrays are only valid up to the visible count).  N is not a multiple of 256."""
+    n = {"specks_and_giants": 20_003, "giants_only": 12, "mostly_culled": 9_001}[case]
+    sc = scenes.synthetic_scene(n, 0.004, 0.2, 77 + n)
+    cam = lego_camera(cameras, frame=1, width=256, height=256)
+    if case == "specks_and_giants":
+        sc["scales"][::997] = 6.0                        # 21 giants among the specks
+    elif case == "giants_only":
+        sc["scales"][:] = 8.0
+        sc["means"] *= 0.2
+    else:
+        centre = np.asarray(cam["camera_center"], np.float32)
+        away = sc["means"] - centre                      # mirror four of five through the camera: behind it
+        keep = np.arange(n) % 5 == 0
+        sc["means"][~keep] = centre - away[~keep]
+    kw = render_kwargs(sc, cam, width=256, height=256)
+    _, got, ref = _both(oracle, kw)
+    parity.compare_forward(got, ref)
+    D = int(parity.to_np(got[2]["point_list"]).size)
+    if case == "giants_only":
+        assert D == n * 256                              # every Gaussian covers the whole 16 x 16 tile grid
+    if case == "mostly_culled":
+        assert (parity.to_np(got[2]["radii"]) > 0).sum() < n // 3 and D > 0
+
+
 def test_huge_gaussian_covers_all_tiles(oracle, cameras, scenes):
     sc = scenes.synthetic_scene(50, 0.05, 0.5, 33)
     sc["scales"][0] = 5.0
