@@ -79,7 +79,8 @@ def stage_bytes(N, Nv, D, P, Tn):
     tile) for the stages the reference has, and the same counting rule for the stages of our own binning
     design, priced from the item widths and pass counts the library really uses (api.hip): depth items are
     8 bytes (4 passes: histogram read + scatter read + write); tile items are 4 bytes when tile bits + id bits <= 32 (C3: 12 + 20),
-    else 8, ceil(tile bits / 8) passes, the last of which writes the 4-byte point_list instead of items."""
+    else 8, ceil(tile bits / 8) passes, the first of which has no histogram read (the expansion leaves its histograms) and the last
+    of which writes the 4-byte point_list instead of items; the depth-order offsets are one read of the sorted counts."""
     tb = max(1, int(np.ceil(np.log2(max(2, Tn)))))
     id_bits = max(1, int(np.ceil(np.log2(max(2, N)))))
     ib = 4 if tb + id_bits <= 32 else 8
@@ -88,9 +89,9 @@ def stage_bytes(N, Nv, D, P, Tn):
         "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv,
         "scan": 8 * N,
         "depth_sort": 4 * 24 * N,
-        "depth_scan": 16 * N,
-        "expand": 20 * Nv + ib * D,
-        "tile_sort": (npass - 1) * 3 * ib * D + (2 * ib + 4) * D + 8 * Tn,
+        "depth_scan": 4 * N,
+        "expand": 16 * Nv + ib * D,
+        "tile_sort": ((ib + 4) * D if npass == 1 else 2 * ib * D + (npass - 2) * 3 * ib * D + (2 * ib + 4) * D) + 8 * Tn,
         "ranges": 0,
         "blend_fwd": 44 * D + 8 * Tn + 24 * P,
         "bwd_prep": 64 * N,
