@@ -295,8 +295,9 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.doff = c.take<int32_t>((size_t)N);
     w.scan_tmp = c.take<int32_t>((size_t)gsr_div_up(N, 256) + 4);
     w.hist = c.take<int32_t>(256 * ((size_t)gsr_radix_blocks(N) + 1));
-    w.acc[0] = c.take<int32_t>(2 * gsr_radix_acc_ints(N)); // both passes' accumulators, contiguous: preprocess clears them in one go
+    w.acc[0] = c.take<int32_t>(3 * gsr_radix_acc_ints(N)); // the accumulators of both pass parities and of the first active pass, contiguous: preprocess clears them in one go
     w.acc[1] = w.acc[0] ? w.acc[0] + gsr_radix_acc_ints(N) : nullptr;
+    w.acc_first = w.acc[0] ? w.acc[0] + 2 * gsr_radix_acc_ints(N) : nullptr;
     w.sum4096 = c.take<int32_t>((size_t)gsr_div_up(N, 4096) + 4);
     w.bytes = c.off + 256;
     return w;
@@ -365,7 +366,8 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     // (preprocess left one partial sum per 256 Gaussians in scan_tmp: one launch)
     // (its first wave also turns the per-block depth extremes preprocess left into the depth sort's pass plan, on the device)
     rb->pinned[1] = 4; // overwritten by the scan's control workgroup with the number of depth passes this frame needs
-    HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s, ws.blk_minmax, ws.depth_ctl));
+    if (gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s, ws.blk_minmax, ws.depth_ctl));
+    else HIP_TRY(gsr_launch_scan_ctl_hist(geom->tiles_touched, geom->point_offsets, ws, N, rb->pinned, s)); // + the first active depth pass's histogram
     mark(st, 2, s);
     HIP_TRY(hipEventRecord(rb->ev, s));
     // Work that does not need D goes out before the host waits: Gaussians by depth bits (stable from id order, four 8-bit

@@ -48,6 +48,7 @@ struct GeomWs {
     int32_t *scan_tmp;    // [N / 256 + 4] partial sums for the scans (preprocess writes one per 256 Gaussians)
     int32_t *hist;        // [nb(N)][256] radix block histograms
     int32_t *acc[2];      // [gsr_radix_acc_ints(N)] each: digit + super-block totals of a pass; consecutive passes alternate
+    int32_t *acc_first;   // [gsr_radix_acc_ints(N)] behind acc[1]: the first ACTIVE depth pass's accumulators (filled beside the id-order scan)
     int32_t *sum4096;     // [N / 4096 + 1] tile pairs per 4096 depth-sorted Gaussians (depth_block_offsets_kernel; scan_tmp holds the 256-level)
     size_t bytes;
 };
@@ -64,6 +65,7 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
                            bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s,
                            const uint32_t *blk_minmax = nullptr, void *depth_ctl = nullptr /* mode 0: also derive the depth sort's DepthCtl */);
 hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes = 4 /* the last `launch_passes` of the four */);
+hipError_t gsr_launch_scan_ctl_hist(const int32_t *tiles_touched, int32_t *point_offsets, const GeomWs &ws, int64_t n, int32_t *total_out, hipStream_t s);
 #define GSR_SMALL_SORT_N 8192          // up to this many Gaussians one workgroup sorts, carries and scans (scan_sort.hip)
 bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes the depth-order offsets (no separate scan)
 

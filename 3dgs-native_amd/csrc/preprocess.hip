@@ -306,7 +306,7 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
                        g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, ws.acc[0],
-                       2 * (int)gsr_radix_acc_ints(sc.N) /* acc[0] and acc[1]: the depth sort may start at a later pass */, ws.scan_tmp, g.sh_dir_grad,
+                       3 * (int)gsr_radix_acc_ints(sc.N) /* acc[0], acc[1] (the depth sort may start at a later pass) and acc_first */, ws.scan_tmp, g.sh_dir_grad,
                        ws.blk_minmax, gsr_debug_flags);
     return hipGetLastError();
 }

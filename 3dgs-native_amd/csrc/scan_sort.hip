@@ -142,7 +142,9 @@ __device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict
         c.n_vis = s_nv[0] + s_nv[1] + s_nv[2] + s_nv[3];
         c.pad[0] = c.pad[1] = c.pad[2] = 0;
         if (lo > hi) { c.min_bits = 0xFFFFFFFFu; c.range = 0u; } // nothing visible: every key is 0, one pass (it carries the rectangles)
-        else { c.min_bits = lo; c.range = hi - lo + 1u; }
+        // (the low byte of the subtrahend is zero, so the key's lowest digit is the raw depth bits' lowest byte whatever the frame's
+        // minimum turns out to be: the first active pass's histogram needs no plan -- scan_ctl_hist_kernel)
+        else { c.min_bits = lo & ~255u; c.range = hi - c.min_bits + 1u; }
         const int nbits = 32 - __builtin_clz(c.range | 1u);      // keys are 0 .. range
         c.npass = force_npass > 0 ? force_npass : max(1, (nbits + 7) / 8); // forced (tests: GSR_DEBUG bit 8 = always four): same order
         c.first = 4 - c.npass;
@@ -152,17 +154,12 @@ __device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict
 }
 
 template <int MODE, int SUMS_PER_UNIT>
-__global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
-                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out,
-                                                         const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass)
+__device__ __forceinline__ void scan_final_block(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums, int32_t *__restrict__ out,
+                                                 int64_t n, int32_t *total_out, int block)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wid = (int64_t)block * 4 + (threadIdx.x >> 6);
     const int64_t base = wid * SCAN_WAVE_ITEMS;
-    if (ctl && blockIdx.x == gridDim.x - 1) { // one extra workgroup, launched for this alone: off the scan's critical path
-        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass, total_out);
-        return;
-    }
     if (base >= n) return;
     // all 16 rounds are loaded before anything else: left to itself the compiler emits load -> wait -> scan -> store per
     // round (the stores' branches fence the loads), a chain of 16 memory round trips per wave
@@ -205,6 +202,18 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
     if (total_out && base + SCAN_WAVE_ITEMS >= n && ((n - 1 - base) & 63) == lane) *total_out = total;
 }
 
+template <int MODE, int SUMS_PER_UNIT>
+__global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
+                                                         int32_t *__restrict__ out, int64_t n, int32_t *total_out,
+                                                         const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass)
+{
+    if (ctl && blockIdx.x == gridDim.x - 1) { // one extra workgroup, launched for this alone: off the scan's critical path
+        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass, total_out);
+        return;
+    }
+    scan_final_block<MODE, SUMS_PER_UNIT>(in, wave_sums, out, n, total_out, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // stable radix pass (4..8-bit digit) on 64-bit items
 // ---------------------------------------------------------------------------------------------
@@ -228,6 +237,8 @@ struct DepthPass {
     const DepthCtl *ctl;
     int pass;            // 0 .. 3
     uint64_t *buf[2];    // ping-pong buffers; the first ACTIVE pass reads buf[0]
+    int32_t *acc_first;  // the accumulators of the first ACTIVE pass, whichever pass that is: its histogram is made ahead of the plan,
+                         // beside the id-order scan (scan_ctl_hist_kernel), into an array of its own
     int launched_first;  // the host launched the passes launched_first .. 3 only (its guess from the previous frame): if this
                          // frame needs an earlier one (ctl->first < launched_first), every launched pass leaves the data alone
                          // and the host, told by the readback, launches all four
@@ -239,30 +250,16 @@ __device__ __forceinline__ int radix_digit(ItemT item, int shift, uint32_t kmin,
     else return (int)((item >> shift) & ((1 << BITS) - 1));
 }
 
-template <int RADIX_ITEMS, int BITS, typename ItemT, bool DEPTH = false>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int32_t *__restrict__ acc,
-                                                         int64_t n, int shift, int sb, DepthPass dp)
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool DEPTH>
+__device__ __forceinline__ void radix_hist_block(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int32_t *__restrict__ acc, int64_t n, int shift,
+                                                 int sb, int block, uint32_t kmin, uint32_t krange, bool drop_culled)
 {
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     constexpr int RADIX = 1 << BITS;
-    uint32_t kmin = 0u, krange = 0u;
-    bool drop_culled = false;
-    if constexpr (DEPTH) {
-        const DepthCtl c = *dp.ctl;
-        if (dp.pass < c.first || c.first < dp.launched_first) return; // this frame's keys need fewer passes / more than were launched
-        const int rel = dp.pass - c.first;
-        in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
-        shift = 8 * rel;
-        kmin = c.min_bits; krange = c.range;
-        // the first active pass reads all n items and drops the culled ones; the later passes see the n_vis survivors only
-        drop_culled = rel == 0;
-        if (rel > 0) n = c.n_vis;
-        if ((int64_t)blockIdx.x * CHUNK >= n) return;
-    }
     __shared__ int h[RADIX];
     if (threadIdx.x < RADIX) h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * CHUNK;
+    const int64_t base = (int64_t)block * CHUNK;
     // loads first, LDS atomics after: otherwise every round waits for its own load (RADIX_ITEMS serial round trips)
     ItemT item[RADIX_ITEMS];
 #pragma unroll
@@ -280,8 +277,48 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     __syncthreads();
     if (threadIdx.x < RADIX) {
         const int c = h[threadIdx.x];
-        hist[(size_t)blockIdx.x * RADIX + threadIdx.x] = c;
-        if (c) atomicAdd(&acc[256 + (blockIdx.x / sb) * 256 + threadIdx.x], c);
+        hist[(size_t)block * RADIX + threadIdx.x] = c;
+        if (c) atomicAdd(&acc[256 + (block / sb) * 256 + threadIdx.x], c);
+    }
+}
+
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool DEPTH = false>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict__ in, int32_t *__restrict__ hist, int32_t *__restrict__ acc,
+                                                         int64_t n, int shift, int sb, DepthPass dp)
+{
+    constexpr int CHUNK = 256 * RADIX_ITEMS;
+    uint32_t kmin = 0u, krange = 0u;
+    if constexpr (DEPTH) {
+        const DepthCtl c = *dp.ctl;
+        if (dp.pass < c.first || c.first < dp.launched_first) return; // this frame's keys need fewer passes / more than were launched
+        const int rel = dp.pass - c.first;
+        if (rel == 0) return; // the first active pass's histogram exists already (scan_ctl_hist_kernel)
+        in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
+        shift = 8 * rel;
+        kmin = c.min_bits; krange = c.range;
+        n = c.n_vis; // the first active pass dropped the culled ones: the later passes see the n_vis survivors only
+        if ((int64_t)blockIdx.x * CHUNK >= n) return;
+    }
+    radix_hist_block<RADIX_ITEMS, BITS, ItemT, DEPTH>(in, hist, acc, n, shift, sb, (int)blockIdx.x, kmin, krange, false);
+}
+
+// The id-order scan behind preprocess (scan_final_kernel<0, 4>), the depth sort's pass plan (its control workgroup) and the
+// histogram of the depth sort's first ACTIVE pass in ONE launch.  That histogram does not depend on the plan: the first active
+// pass always reads the items preprocess wrote, counts the visible ones, and its digit is the lowest byte of the raw depth
+// bits (DepthCtl.min_bits has a zero low byte).  The scan's workgroups come first in the grid (D reaches the host early), the
+// histogram's fill the chip behind them: 5 us at C3, 25 us at C5 no longer stand between preprocess and the sort.
+template <int HIST_ITEMS>
+__global__ __launch_bounds__(256) void scan_ctl_hist_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums, int32_t *__restrict__ out,
+                                                            int64_t n, int32_t *total_out, const uint32_t *__restrict__ blk_minmax, int nblk,
+                                                            DepthCtl *__restrict__ ctl, int force_npass, int nb_scan,
+                                                            const uint64_t *__restrict__ items, int32_t *__restrict__ hist, int32_t *__restrict__ acc_first, int sb)
+{
+    if ((int)blockIdx.x < nb_scan) {
+        scan_final_block<0, 4>(in, wave_sums, out, n, total_out, (int)blockIdx.x);
+    } else if ((int)blockIdx.x == nb_scan) {
+        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass, total_out);
+    } else {
+        radix_hist_block<HIST_ITEMS, 8, uint64_t, true>(items, hist, acc_first, n, 0, sb, (int)blockIdx.x - nb_scan - 1, 0u, 0xFFFFFFFFu, true);
     }
 }
 
@@ -289,8 +326,13 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
 // kernels after all: with only the two-level sums a scatter block read ~1.5 sqrt(nb) rows (68 KB per block, 0.5 GB per pass at
 // C5: tile partition 395 -> 435 us).  One workgroup turns the super-block rows into exclusive prefixes in place and writes the
 // digit totals to acc[0..255]; super-blocks are then a fixed 32 blocks, so a scatter block reads 2 + (< 32) rows.
-__global__ __launch_bounds__(1024) void radix_superscan_kernel(int32_t *__restrict__ acc, int nsuper)
+__global__ __launch_bounds__(1024) void radix_superscan_kernel(int32_t *__restrict__ acc, int nsuper, DepthPass dp)
 {
+    if (dp.ctl) { // a depth pass: skipped passes have nothing to scan, the first active one keeps its sums in an array of its own
+        const DepthCtl c = *dp.ctl;
+        if (dp.pass < c.first || c.first < dp.launched_first) return;
+        if (dp.pass == c.first) acc = dp.acc_first;
+    }
     __shared__ int4 s_part[16][64];
     const int q = threadIdx.x & 63, g = threadIdx.x >> 6; // 64 threads x 4 digits per row; 16 groups, a contiguous share of rows each
     const int per = (nsuper + 15) / 16, t0 = g * per, t1 = min(nsuper, t0 + per);
@@ -392,6 +434,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         const DepthCtl c = *dp.ctl;
         if (dp.pass < c.first || c.first < dp.launched_first) return;
         const int rel = dp.pass - c.first;
+        if (rel == 0) acc = dp.acc_first; // (see scan_ctl_hist_kernel)
         in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
         out = reinterpret_cast<ItemT *>(dp.buf[(rel + 1) & 1]);
         shift = 8 * rel;
@@ -1069,11 +1112,11 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
     }
     if (g.small) {
-        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
+        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
                            n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb);
+        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
                            shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
@@ -1126,6 +1169,24 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
     return radix_pass_any<uint64_t, true>((const uint64_t *)in, (uint64_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s, hist_ready);
 }
 
+// The id-order scan of tiles_touched into point_offsets (D to the pinned host word), the depth sort's pass plan and the first
+// active depth pass's histogram, one launch (scan_ctl_hist_kernel).  Not for the small-scene path (gsr_small_depth_path).
+hipError_t gsr_launch_scan_ctl_hist(const int32_t *tiles_touched, int32_t *point_offsets, const GeomWs &ws, int64_t n, int32_t *total_out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const int nb_scan = ((int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS) + 3) / 4, nblk = (int)gsr_div_up(n, 256);
+    const int force = (gsr_debug_flags & 256) ? 4 : 0; // GSR_DEBUG bit 8: always four depth passes (tests: same order)
+    const PassGeom g = pass_geom(n);
+    DepthCtl *ctl = (DepthCtl *)ws.depth_ctl;
+    if (g.small)
+        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256>), dim3(nb_scan + 1 + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
+                           total_out, ws.blk_minmax, nblk, ctl, force, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
+    else
+        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_CHUNK / 256>), dim3(nb_scan + 1 + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
+                           total_out, ws.blk_minmax, nblk, ctl, force, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
+    return hipGetLastError();
+}
+
 // The depth sort: Gaussians by depth bits, stable from id order.  Four 8-bit passes over the 64-bit (depth bits << 32 | id) items
 // are launched; how many of them this frame's depth range needs is decided on the device (DepthCtl, filled by the id-order scan),
 // the others return at once.  The last pass writes, instead of the sorted items, what the rest of the pipeline reads: the ids,
@@ -1144,13 +1205,17 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int
     const int zero_n = (int)gsr_radix_acc_ints(n);
     const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted, n};
     for (int pass = 4 - launch_passes; pass < 4; ++pass) {
-        const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}, 4 - launch_passes};
-        // pass p accumulates into acc[p & 1] (cleared by preprocess for p = 0) and clears the other one for pass p + 1
+        const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}, ws.acc_first, 4 - launch_passes};
+        // pass p accumulates into acc[p & 1] (both cleared by preprocess) and clears the other one for pass p + 1 -- except the
+        // first ACTIVE pass, whose histogram and sums were made beside the id-order scan (gsr_launch_scan_ctl_hist) in acc_first.
+        // The first LAUNCHED pass is either skipped by the plan or the first active one: its histogram kernel is not launched.
+        const bool no_hist = pass == 4 - launch_passes;
         if (pass < 3)
             radix_pass_launch<8, uint64_t, false, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, ws.acc[(pass + 1) & 1], zero_n,
-                                                               ScatterCarry{}, ScatterFinal{}, s, dp);
+                                                               ScatterCarry{}, ScatterFinal{}, s, dp, no_hist);
         else
-            radix_pass_launch<8, uint64_t, true, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, nullptr, 0, carry, ScatterFinal{}, s, dp);
+            radix_pass_launch<8, uint64_t, true, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, nullptr, 0, carry, ScatterFinal{}, s, dp,
+                                                              no_hist);
     }
     return hipGetLastError();
 }
