@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void expand_blocks_kernel(const uint32_t *__re
                                                             int64_t D, int id_shift, int chunk, int digit_mask, int32_t *__restrict__ hist,
                                                             int32_t *__restrict__ acc, int sb)
 {
-    __shared__ int s_off[256];
+    __shared__ int s_off[257]; // [256] = the end of the block's items
     __shared__ TileRect s_rect[256];
     __shared__ uint32_t s_gid[256];
     __shared__ float s_inv[256]; // 1 / (rectangle width in tiles)
@@ -887,6 +887,7 @@ __global__ __launch_bounds__(256) void expand_blocks_kernel(const uint32_t *__re
         s_gid[tid] = id;
         s_inv[tid] = wd > 0 ? 1.0f / (float)wd : 0.0f;
         const int end = base + tot;
+        if (tid == 255) s_off[256] = end;
         int next_cnt = 0;
         if (end < hi && B + 1 < nsum) {
             const int64_t k = (int64_t)(B + 1) * 256 + tid;
@@ -897,24 +898,61 @@ __global__ __launch_bounds__(256) void expand_blocks_kernel(const uint32_t *__re
         }
         __syncthreads();
         const int j0 = max(lo, base), j1 = min(hi, end);
-        for (int j = (j0 & ~255) + tid; j < j1; j += 256) { // 256 consecutive items per step, aligned: coalesced stores
-            if (j < j0) continue;
-            int p = 0; // last entry with off <= j
+        // 32 bytes of consecutive items per thread (eight 4-byte or four 8-byte items; a wave writes 2 KB of consecutive items as
+        // 16-byte pieces -- 64 bytes per thread measured 25 % slower at C5): one 8-step search of the offsets for the thread's first
+        // item, then the walk is incremental -- next column, next row, next Gaussian -- instead of a search and a quotient per item
+        constexpr int PT = 32 / (int)sizeof(ItemT);
+        for (int jb = (j0 & ~(PT - 1)) + tid * PT; jb < j1; jb += 256 * PT) {
+            const int jf = max(jb, j0); // the thread's first item inside [j0, j1)
+            int p = 0; // last entry with off <= jf
 #pragma unroll
             for (int step = 128; step >= 1; step >>= 1)
-                if (s_off[p + step] <= j) p += step;
-            const TileRect r = s_rect[p];
-            const int t = j - s_off[p];
-            const int rw = (int)r.x1 - (int)r.x0;
+                if (s_off[p + step] <= jf) p += step;
+            TileRect r = s_rect[p];
+            uint32_t gid = s_gid[p];
+            int next_off = s_off[p + 1];
+            int rw = (int)r.x1 - (int)r.x0;
             // row-major walk: y = t / rw, x = t % rw (reference forward.py:546-548); t < 2^24, so the quotient comes from one float
             // multiply by the Gaussian's 1 / rw and a +-1 correction
+            const int t = jf - s_off[p];
             int y = (int)((float)t * s_inv[p]);
             int x = t - y * rw;
             if (x < 0) { --y; x += rw; }
             else if (x >= rw) { ++y; x -= rw; }
-            const uint32_t tile = (uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x);
-            tile_items[j] = (ItemT)(((ItemT)tile << id_shift) | (ItemT)s_gid[p]);
-            atomicAdd(&s_h[tile & (uint32_t)digit_mask], 1);
+            ItemT outv[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const int j = jb + u;
+                outv[u] = 0;
+                if (j >= jf && j < j1) {
+                    if (j >= next_off) { // the next Gaussian with items (empty ones share their successor's offset)
+                        do { ++p; next_off = s_off[p + 1]; } while (j >= next_off);
+                        r = s_rect[p];
+                        gid = s_gid[p];
+                        rw = (int)r.x1 - (int)r.x0;
+                        x = 0; y = 0;
+                    }
+                    const uint32_t tile = (uint32_t)(((int)r.y0 + y) * grid_x + (int)r.x0 + x);
+                    outv[u] = (ItemT)(((ItemT)tile << id_shift) | (ItemT)gid);
+                    atomicAdd(&s_h[tile & (uint32_t)digit_mask], 1);
+                    if (++x == rw) { x = 0; ++y; }
+                }
+            }
+            if (jb >= j0 && jb + PT <= j1) { // whole and 32-byte aligned: 16-byte stores
+                constexpr int PER = 16 / (int)sizeof(ItemT);
+                uint4 *dst = reinterpret_cast<uint4 *>(tile_items + jb);
+#pragma unroll
+                for (int q = 0; q < PT / PER; ++q) {
+                    uint4 v;
+                    if constexpr (sizeof(ItemT) == 4) v = make_uint4((uint32_t)outv[4 * q], (uint32_t)outv[4 * q + 1], (uint32_t)outv[4 * q + 2], (uint32_t)outv[4 * q + 3]);
+                    else v = make_uint4((uint32_t)outv[2 * q], (uint32_t)((uint64_t)outv[2 * q] >> 32), (uint32_t)outv[2 * q + 1], (uint32_t)((uint64_t)outv[2 * q + 1] >> 32));
+                    dst[q] = v;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PT; ++u)
+                    if (jb + u >= j0 && jb + u < j1) tile_items[jb + u] = outv[u];
+            }
         }
         if (end >= hi) break;
         base = end; // the next block starts where this one ends
