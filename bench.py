@@ -87,8 +87,8 @@ def stage_bytes(N, Nv, D, P, Tn):
     npass = (tb + 7) // 8
     return {
         "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv,
-        "scan": 8 * N,
-        "depth_sort": 4 * 24 * N,
+        "scan": 8 * N + 8 * N,             # + the first depth pass's histogram read (made in the scan's launch)
+        "depth_sort": 4 * 24 * N - 8 * N,
         "depth_scan": 4 * N,
         "expand": 16 * Nv + ib * D,
         "tile_sort": ((ib + 4) * D if npass == 1 else 2 * ib * D + (npass - 2) * 3 * ib * D + (2 * ib + 4) * D) + 8 * Tn,
