@@ -186,7 +186,7 @@ Readback *readback_acquire()
         }
     Readback *r = new Readback;
     r->dev = dev;
-    if (hipHostMalloc((void **)&r->pinned, 64, hipHostMallocMapped) != hipSuccess ||       // device-writable
+    if (hipHostMalloc((void **)&r->pinned, 256, hipHostMallocMapped) != hipSuccess ||       // device-writable
         hipEventCreateWithFlags(&r->ev, hipEventDisableTiming) != hipSuccess) {
         if (r->pinned) (void)hipHostFree(r->pinned);
         delete r;
@@ -289,7 +289,7 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.sort_tmp = c.take<uint64_t>((size_t)N);
     w.id_sorted = c.take<uint32_t>((size_t)N);
     w.blk_minmax = c.take<uint32_t>(4 * (size_t)gsr_div_up(N, 256) + 4);
-    w.depth_ctl = c.take<uint32_t>(8);
+    w.depth_ctl = w.blk_minmax ? w.blk_minmax + 4 * (size_t)gsr_div_up(N, 256) : nullptr; // the uint4 behind the last block's (preprocess clears it)
     w.rect_sorted = c.take<TileRect>((size_t)N);
     w.cnt_sorted = c.take<int32_t>((size_t)N);
     w.doff = c.take<int32_t>((size_t)N);
@@ -365,7 +365,8 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     // the scan's last wave stores D = point_offsets[N-1] straight into the pinned host word
     // (preprocess left one partial sum per 256 Gaussians in scan_tmp: one launch)
     // (its first wave also turns the per-block depth extremes preprocess left into the depth sort's pass plan, on the device)
-    rb->pinned[1] = 4; // overwritten by the scan's control workgroup with the number of depth passes this frame needs
+    // (words 2 .. : the visible depth extremes, one pair per control workgroup of the scan's launch -- the host derives from them
+    // how many depth passes this frame needed, its launch guess for the next)
     if (gsr_small_depth_path(N)) HIP_TRY(gsr_launch_scan(geom->tiles_touched, nullptr, geom->point_offsets, ws.scan_tmp, N, 0, rb->pinned, true, s, ws.blk_minmax, ws.depth_ctl));
     else HIP_TRY(gsr_launch_scan_ctl_hist(geom->tiles_touched, geom->point_offsets, ws, N, rb->pinned, s)); // + the first active depth pass's histogram
     mark(st, 2, s);
@@ -380,7 +381,15 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     HIP_TRY(gsr_launch_depth_sort(ws, N, s, guess));
     HIP_TRY(hipEventSynchronize(rb->ev)); // D (and the pass count) are on the host; the GPU keeps sorting
     const int32_t last = *rb->pinned;
-    const int needed = std::min(4, std::max(1, (int)rb->pinned[1]));
+    int needed = 4;
+    if (!gsr_small_depth_path(N)) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int k = 0, K = gsr_depth_ctl_wgs(N); k < K; ++k) {
+            lo = std::min(lo, (uint32_t)rb->pinned[2 + 2 * k]);
+            hi = std::max(hi, (uint32_t)rb->pinned[3 + 2 * k]);
+        }
+        needed = gsr_depth_plan(lo, hi, (gsr_debug_flags & 256) ? 4 : 0).npass;
+    }
     if (needed > guess && !gsr_small_depth_path(N)) HIP_TRY(gsr_launch_depth_sort(ws, N, s, 4));
     mark(st, 3, s);
     // (the depth-order offsets are made by gsr_forward_render, next to their one reader -- the expansion; the alternative path of

@@ -41,7 +41,7 @@ struct GeomWs {
     uint64_t *sort_tmp;   // [N] ping-pong partner of depth_item
     uint32_t *id_sorted;  // [N] Gaussian ids in depth order (written by the last depth-sort pass)
     uint32_t *blk_minmax; // [4 * ceil(N / 256)] per preprocess block: smallest / largest visible depth bits, visible count, -
-    void *depth_ctl;      // DepthCtl (scan_sort.hip): this frame's depth range and pass count, decided on the device
+    void *depth_ctl;      // DepthCtlRaw (scan_sort.hip), the uint4 behind the last block's extremes: this frame's visible depth range and count
     TileRect *rect_sorted; // [N] tile rectangles in depth order (written by the last depth-sort pass)
     int32_t *cnt_sorted;  // [N] tile counts in depth order (same pass)
     int32_t *doff;        // [N] exclusive tile-pair offsets in depth order
@@ -59,6 +59,26 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
 
 // Device-wide scan of int32.  mode 0: out[i] = inclusive scan of in[i].
 // mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
+// The depth sort's pass plan from the frame's visible depth extremes (bit patterns of positive floats).  Shared by the device
+// (every depth kernel derives it from DepthCtlRaw) and the host (its launch guess for the next frame, from the pinned words).
+struct DepthPlan {
+    uint32_t min_bits, range; // key = umin(bits - min_bits, range); min_bits has a zero low byte (see scan_ctl_hist_kernel)
+    int npass, first;         // passes first .. 3 are active, first = 4 - npass
+};
+static inline __host__ __device__ DepthPlan gsr_depth_plan(uint32_t lo, uint32_t hi, int force_npass)
+{
+    DepthPlan p;
+    if (lo > hi) { p.min_bits = 0xFFFFFFFFu; p.range = 0u; } // nothing visible: every key is 0, one pass (it carries the rectangles)
+    else { p.min_bits = lo & ~255u; p.range = hi - p.min_bits + 1u; }
+    int nbits = 0;
+    for (uint32_t r = p.range | 1u; r; r >>= 1) ++nbits; // keys are 0 .. range
+    p.npass = force_npass > 0 ? force_npass : (nbits + 7) / 8 < 1 ? 1 : (nbits + 7) / 8; // forced (tests: GSR_DEBUG bit 8 = always four): same order
+    p.first = 4 - p.npass;
+    return p;
+}
+#define GSR_DEPTH_CTL_WGS_MAX 16
+// how many workgroups of the scan's launch reduce the per-block extremes (2048 blocks each at most 16: one round of loads per thread)
+static inline int gsr_depth_ctl_wgs(int64_t N) { const int64_t nblk = (N + 255) / 256; const int64_t k = (nblk + 2047) / 2048; return (int)(k < 1 ? 1 : k > GSR_DEPTH_CTL_WGS_MAX ? GSR_DEPTH_CTL_WGS_MAX : k); }
 #define GSR_SCAN_WAVE_ITEMS 1024   // items per wave-sized scan unit; scratch = one int32 per unit
 hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *out, int32_t *block_tmp,
                            int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */,

@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         reinterpret_cast<uint4 *>(blk_minmax)[blockIdx.x] = make_uint4(min(min(s_dmin[0], s_dmin[1]), min(s_dmin[2], s_dmin[3])),
                                                                        max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3])),
                                                                        s_dvis[0] + s_dvis[1] + s_dvis[2] + s_dvis[3], 0u);
+        // the slot behind the last block is the frame's DepthCtlRaw (scan_sort.hip): cleared here, combined into by the scan's launch
+        if (blockIdx.x == 0) reinterpret_cast<uint4 *>(blk_minmax)[gridDim.x] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian

@@ -94,37 +94,55 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t *__restr
 // bits themselves (positive floats order like their bit patterns), culled Gaussians (bits 0xFFFFFFFF) all at `range`, behind
 // every visible one, in id order -- and only the low `8 * npass` bits of it can differ.  A typical scene spans less than two
 // octaves of depth around the camera distance: range < 2^24, three 8-bit passes instead of four.
-struct DepthCtl {
+struct DepthCtl { // what a depth kernel works with, derived from DepthCtlRaw when it starts (depth_ctl_load)
     uint32_t min_bits, range;
     int32_t npass, first; // passes 0 .. 3 are launched; pass p sorts digit p - first, passes below `first` = 4 - npass exit at once
     int32_t n_vis;        // visible Gaussians: the first active pass drops the culled ones, the later passes move n_vis items
-    int32_t pad[3];
 };
+// In memory (the uint4 behind the last block's extremes, cleared by preprocess): the frame's extremes and visible count, combined
+// by atomics from the few workgroups of the scan's launch that reduce the per-block values.  The minimum is kept complemented so
+// that zero is the identity of every field.
+struct DepthCtlRaw {
+    uint32_t inv_min, max_bits;
+    int32_t n_vis;
+    uint32_t pad;
+};
+__device__ __forceinline__ DepthCtl depth_ctl_load(const DepthCtlRaw *__restrict__ raw, int force_npass)
+{
+    const uint4 r = *reinterpret_cast<const uint4 *>(raw);
+    const DepthPlan p = gsr_depth_plan(~r.x, r.y, force_npass);
+    DepthCtl c;
+    c.min_bits = p.min_bits; c.range = p.range; c.npass = p.npass; c.first = p.first; c.n_vis = (int32_t)r.z;
+    return c;
+}
 
-// Run by ONE wave of the id-order scan (which follows preprocess in the stream and precedes the depth passes): preprocess left
-// the smallest and largest visible depth bits of every 256-Gaussian block (0xFFFFFFFF / 0 for a block without a visible one).
-__device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass,
+// Run by a few workgroups of the id-order scan's launch (which follows preprocess in the stream and precedes the depth passes):
+// preprocess left the smallest and largest visible depth bits of every 256-Gaussian block (0xFFFFFFFF / 0 for a block without a
+// visible one) and its visible count.  Workgroup k of K reduces its share of the blocks (at most 2048 when K < 16: one round of
+// loads per thread -- as ONE workgroup this was ten dependent rounds at 5 M Gaussians, 16 us that the whole launch waited for)
+// and adds it to DepthCtlRaw; its extremes also go to the pinned host words 2 + 2k, 3 + 2k (the host's launch guess for the next
+// frame: api.hip).
+__device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtlRaw *__restrict__ raw, int k, int K,
                                                       int32_t *host_words)
 {
-    // one 256-thread workgroup; 16-byte loads (two blocks each), all of a thread's loads in flight before anything is combined:
-    // 8 bytes x N / 256 (31 KB at a million Gaussians) in one or two memory round trips
     __shared__ uint32_t s_lo[4], s_hi[4];
     __shared__ int s_nv[4];
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     int nv = 0;
     const uint4 *p4 = reinterpret_cast<const uint4 *>(blk_minmax); // per block {min, max, visible count, -}
-    for (int b0 = 0; b0 < nblk; b0 += 256 * 8) {
+    const int per = (nblk + K - 1) / K, b_begin = k * per, b_end = min(nblk, b_begin + per);
+    for (int b0 = b_begin; b0 < b_end; b0 += 256 * 8) {
         uint4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int b = b0 + k * 256 + (int)threadIdx.x;
-            v[k] = b < nblk ? p4[b] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        for (int q = 0; q < 8; ++q) {
+            const int b = b0 + q * 256 + (int)threadIdx.x;
+            v[q] = b < b_end ? p4[b] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            lo = min(lo, v[k].x);
-            hi = max(hi, v[k].y);
-            nv += (int)v[k].z;
+        for (int q = 0; q < 8; ++q) {
+            lo = min(lo, v[q].x);
+            hi = max(hi, v[q].y);
+            nv += (int)v[q].z;
         }
     }
 #pragma unroll
@@ -138,18 +156,11 @@ __device__ __forceinline__ void depth_ctl_from_blocks(const uint32_t *__restrict
     if (threadIdx.x == 0) {
         lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
         hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-        DepthCtl c;
-        c.n_vis = s_nv[0] + s_nv[1] + s_nv[2] + s_nv[3];
-        c.pad[0] = c.pad[1] = c.pad[2] = 0;
-        if (lo > hi) { c.min_bits = 0xFFFFFFFFu; c.range = 0u; } // nothing visible: every key is 0, one pass (it carries the rectangles)
-        // (the low byte of the subtrahend is zero, so the key's lowest digit is the raw depth bits' lowest byte whatever the frame's
-        // minimum turns out to be: the first active pass's histogram needs no plan -- scan_ctl_hist_kernel)
-        else { c.min_bits = lo & ~255u; c.range = hi - c.min_bits + 1u; }
-        const int nbits = 32 - __builtin_clz(c.range | 1u);      // keys are 0 .. range
-        c.npass = force_npass > 0 ? force_npass : max(1, (nbits + 7) / 8); // forced (tests: GSR_DEBUG bit 8 = always four): same order
-        c.first = 4 - c.npass;
-        *ctl = c;
-        if (host_words) host_words[1] = c.npass; // beside D in the pinned readback words: the host's launch guess for the next frame
+        nv = s_nv[0] + s_nv[1] + s_nv[2] + s_nv[3];
+        if (~lo) atomicMax(&raw->inv_min, ~lo);
+        if (hi) atomicMax(&raw->max_bits, hi);
+        if (nv) atomicAdd(&raw->n_vis, nv);
+        if (host_words) { host_words[2 + 2 * k] = (int32_t)lo; host_words[3 + 2 * k] = (int32_t)hi; }
     }
 }
 
@@ -205,10 +216,10 @@ __device__ __forceinline__ void scan_final_block(const int32_t *__restrict__ in,
 template <int MODE, int SUMS_PER_UNIT>
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums,
                                                          int32_t *__restrict__ out, int64_t n, int32_t *total_out,
-                                                         const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtl *__restrict__ ctl, int force_npass)
+                                                         const uint32_t *__restrict__ blk_minmax, int nblk, DepthCtlRaw *__restrict__ ctl)
 {
     if (ctl && blockIdx.x == gridDim.x - 1) { // one extra workgroup, launched for this alone: off the scan's critical path
-        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass, total_out);
+        depth_ctl_from_blocks(blk_minmax, nblk, ctl, 0, 1, total_out);
         return;
     }
     scan_final_block<MODE, SUMS_PER_UNIT>(in, wave_sums, out, n, total_out, (int)blockIdx.x);
@@ -234,7 +245,8 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t *__restri
 // (DepthCtl above), which pass this is decides the digit and which of the two ping-pong buffers is the input, and a pass the
 // frame does not need returns at once -- all read from device memory, so the host launches the same four passes every frame.
 struct DepthPass {
-    const DepthCtl *ctl;
+    const DepthCtlRaw *ctl;
+    int force_npass;     // GSR_DEBUG bit 8 (tests): four passes whatever the range
     int pass;            // 0 .. 3
     uint64_t *buf[2];    // ping-pong buffers; the first ACTIVE pass reads buf[0]
     int32_t *acc_first;  // the accumulators of the first ACTIVE pass, whichever pass that is: its histogram is made ahead of the plan,
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
     constexpr int CHUNK = 256 * RADIX_ITEMS;
     uint32_t kmin = 0u, krange = 0u;
     if constexpr (DEPTH) {
-        const DepthCtl c = *dp.ctl;
+        const DepthCtl c = depth_ctl_load(dp.ctl, dp.force_npass);
         if (dp.pass < c.first || c.first < dp.launched_first) return; // this frame's keys need fewer passes / more than were launched
         const int rel = dp.pass - c.first;
         if (rel == 0) return; // the first active pass's histogram exists already (scan_ctl_hist_kernel)
@@ -310,15 +322,15 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
 template <int HIST_ITEMS>
 __global__ __launch_bounds__(256) void scan_ctl_hist_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ wave_sums, int32_t *__restrict__ out,
                                                             int64_t n, int32_t *total_out, const uint32_t *__restrict__ blk_minmax, int nblk,
-                                                            DepthCtl *__restrict__ ctl, int force_npass, int nb_scan,
+                                                            DepthCtlRaw *__restrict__ ctl, int n_ctl, int nb_scan,
                                                             const uint64_t *__restrict__ items, int32_t *__restrict__ hist, int32_t *__restrict__ acc_first, int sb)
 {
     if ((int)blockIdx.x < nb_scan) {
         scan_final_block<0, 4>(in, wave_sums, out, n, total_out, (int)blockIdx.x);
-    } else if ((int)blockIdx.x == nb_scan) {
-        depth_ctl_from_blocks(blk_minmax, nblk, ctl, force_npass, total_out);
+    } else if ((int)blockIdx.x < nb_scan + n_ctl) {
+        depth_ctl_from_blocks(blk_minmax, nblk, ctl, (int)blockIdx.x - nb_scan, n_ctl, total_out);
     } else {
-        radix_hist_block<HIST_ITEMS, 8, uint64_t, true>(items, hist, acc_first, n, 0, sb, (int)blockIdx.x - nb_scan - 1, 0u, 0xFFFFFFFFu, true);
+        radix_hist_block<HIST_ITEMS, 8, uint64_t, true>(items, hist, acc_first, n, 0, sb, (int)blockIdx.x - nb_scan - n_ctl, 0u, 0xFFFFFFFFu, true);
     }
 }
 
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void scan_ctl_hist_kernel(const int32_t *__res
 __global__ __launch_bounds__(1024) void radix_superscan_kernel(int32_t *__restrict__ acc, int nsuper, DepthPass dp)
 {
     if (dp.ctl) { // a depth pass: skipped passes have nothing to scan, the first active one keeps its sums in an array of its own
-        const DepthCtl c = *dp.ctl;
+        const DepthCtl c = depth_ctl_load(dp.ctl, dp.force_npass);
         if (dp.pass < c.first || c.first < dp.launched_first) return;
         if (dp.pass == c.first) acc = dp.acc_first;
     }
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     bool drop_culled = false;
     int64_t n_load = n; // items readable in `in` (the index clamp of the loads)
     if constexpr (DEPTH) {
-        const DepthCtl c = *dp.ctl;
+        const DepthCtl c = depth_ctl_load(dp.ctl, dp.force_npass);
         if (dp.pass < c.first || c.first < dp.launched_first) return;
         const int rel = dp.pass - c.first;
         if (rel == 0) acc = dp.acc_first; // (see scan_ctl_hist_kernel)
@@ -1103,18 +1115,17 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
     const int nw = (int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS); // wave-sized units; block_tmp holds one sum per unit
     const int nb = (nw + 3) / 4;
     (void)items;
-    DepthCtl *ctl = (DepthCtl *)depth_ctl; // only the id-order scan behind preprocess is asked to fill it
+    DepthCtlRaw *ctl = (DepthCtlRaw *)depth_ctl; // only the id-order scan behind preprocess is asked to fill it (one workgroup here)
     const int nblk = (int)gsr_div_up(n, 256);
-    const int force = (gsr_debug_flags & 256) ? 4 : 0; // GSR_DEBUG bit 8: always four depth passes (tests: same order)
     if (mode == 0 && sums_per_256_ready) { // block_tmp already holds one sum per 256 items (preprocess.hip)
-        hipLaunchKernelGGL((scan_final_kernel<0, 4>), dim3(nb + (ctl ? 1 : 0)), dim3(256), 0, s, in, block_tmp, out, n, total_out, blk_minmax, nblk, ctl, force);
+        hipLaunchKernelGGL((scan_final_kernel<0, 4>), dim3(nb + (ctl ? 1 : 0)), dim3(256), 0, s, in, block_tmp, out, n, total_out, blk_minmax, nblk, ctl);
     } else if (mode == 0) {
         hipLaunchKernelGGL(scan_reduce_kernel<0>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
-        hipLaunchKernelGGL((scan_final_kernel<0, 1>), dim3(nb + (ctl ? 1 : 0)), dim3(256), 0, s, in, block_tmp, out, n, total_out, blk_minmax, nblk, ctl, force);
+        hipLaunchKernelGGL((scan_final_kernel<0, 1>), dim3(nb + (ctl ? 1 : 0)), dim3(256), 0, s, in, block_tmp, out, n, total_out, blk_minmax, nblk, ctl);
     } else if (mode == 2) {
         hipLaunchKernelGGL(scan_reduce_kernel<2>, dim3(nb), dim3(256), 0, s, in, block_tmp, n);
         hipLaunchKernelGGL((scan_final_kernel<2, 1>), dim3(nb), dim3(256), 0, s, in, block_tmp, out, n, total_out, (const uint32_t *)nullptr, 0,
-                           (DepthCtl *)nullptr, 0);
+                           (DepthCtlRaw *)nullptr);
     } else {
         return hipErrorInvalidValue;
     }
@@ -1212,16 +1223,15 @@ hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *a
 hipError_t gsr_launch_scan_ctl_hist(const int32_t *tiles_touched, int32_t *point_offsets, const GeomWs &ws, int64_t n, int32_t *total_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    const int nb_scan = ((int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS) + 3) / 4, nblk = (int)gsr_div_up(n, 256);
-    const int force = (gsr_debug_flags & 256) ? 4 : 0; // GSR_DEBUG bit 8: always four depth passes (tests: same order)
+    const int nb_scan = ((int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS) + 3) / 4, nblk = (int)gsr_div_up(n, 256), n_ctl = gsr_depth_ctl_wgs(n);
     const PassGeom g = pass_geom(n);
-    DepthCtl *ctl = (DepthCtl *)ws.depth_ctl;
+    DepthCtlRaw *ctl = (DepthCtlRaw *)ws.depth_ctl;
     if (g.small)
-        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256>), dim3(nb_scan + 1 + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
-                           total_out, ws.blk_minmax, nblk, ctl, force, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
+        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256>), dim3(nb_scan + n_ctl + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
+                           total_out, ws.blk_minmax, nblk, ctl, n_ctl, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
     else
-        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_CHUNK / 256>), dim3(nb_scan + 1 + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
-                           total_out, ws.blk_minmax, nblk, ctl, force, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
+        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_CHUNK / 256>), dim3(nb_scan + n_ctl + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
+                           total_out, ws.blk_minmax, nblk, ctl, n_ctl, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
     return hipGetLastError();
 }
 
@@ -1243,7 +1253,7 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int
     const int zero_n = (int)gsr_radix_acc_ints(n);
     const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted, n};
     for (int pass = 4 - launch_passes; pass < 4; ++pass) {
-        const DepthPass dp{(const DepthCtl *)ws.depth_ctl, pass, {ws.depth_item, ws.sort_tmp}, ws.acc_first, 4 - launch_passes};
+        const DepthPass dp{(const DepthCtlRaw *)ws.depth_ctl, (gsr_debug_flags & 256) ? 4 : 0, pass, {ws.depth_item, ws.sort_tmp}, ws.acc_first, 4 - launch_passes};
         // pass p accumulates into acc[p & 1] (both cleared by preprocess) and clears the other one for pass p + 1 -- except the
         // first ACTIVE pass, whose histogram and sums were made beside the id-order scan (gsr_launch_scan_ctl_hist) in acc_first.
         // The first LAUNCHED pass is either skipped by the plan or the first active one: its histogram kernel is not launched.
