@@ -345,34 +345,55 @@ __global__ __launch_bounds__(1024) void radix_superscan_kernel(int32_t *__restri
         if (dp.pass < c.first || c.first < dp.launched_first) return;
         if (dp.pass == c.first) acc = dp.acc_first;
     }
-    __shared__ int4 s_part[16][64];
-    const int q = threadIdx.x & 63, g = threadIdx.x >> 6; // 64 threads x 4 digits per row; 16 groups, a contiguous share of rows each
-    const int per = (nsuper + 15) / 16, t0 = g * per, t1 = min(nsuper, t0 + per);
+    // Four workgroups, 64 digits each (16 threads x 4 digits per row); 64 groups of threads share the rows, a contiguous run each:
+    // at C5 (246 rows) a group has 4 rows -- one round of loads, kept in registers for the store pass -- where one workgroup of 16
+    // groups walked 16 rows twice (11 us per launch, two launches per frame; now 2 x ~5).
+    __shared__ int4 s_part[64][16];
+    const int ql = threadIdx.x & 15, g = threadIdx.x >> 4, q = (int)blockIdx.x * 16 + ql;
+    const int per = (nsuper + 63) / 64, t0 = g * per, t1 = min(nsuper, t0 + per);
     int4 *rows = reinterpret_cast<int4 *>(acc + 256) + q;
     int4 sum = make_int4(0, 0, 0, 0);
-#pragma unroll 8
-    for (int t = t0; t < t1; ++t) {
-        const int4 v = rows[(size_t)t * 64];
-        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-    }
-    s_part[g][q] = sum;
-    __syncthreads();
-    int4 run = make_int4(0, 0, 0, 0), all = run;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int4 v = s_part[k][q];
-        if (k < g) { run.x += v.x; run.y += v.y; run.z += v.z; run.w += v.w; }
-        all.x += v.x; all.y += v.y; all.z += v.z; all.w += v.w;
-    }
-    if (g == 0) reinterpret_cast<int4 *>(acc)[q] = all;
-    for (int tb = t0; tb < t1; tb += 8) { // eight rows at a time: loads together, then the stores
-        int4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = tb + k < t1 ? rows[(size_t)(tb + k) * 64] : make_int4(0, 0, 0, 0);
+    int4 v[8];
+    const bool held = per <= 8; // the group's rows stay in registers between the two passes
+    if (held) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (tb + k < t1) rows[(size_t)(tb + k) * 64] = run;
+            v[k] = t0 + k < t1 ? rows[(size_t)(t0 + k) * 64] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w; }
+    } else {
+#pragma unroll 8
+        for (int t = t0; t < t1; ++t) {
+            const int4 w = rows[(size_t)t * 64];
+            sum.x += w.x; sum.y += w.y; sum.z += w.z; sum.w += w.w;
+        }
+    }
+    s_part[g][ql] = sum;
+    __syncthreads();
+    int4 run = make_int4(0, 0, 0, 0), all = run;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) {
+        const int4 w = s_part[k][ql];
+        if (k < g) { run.x += w.x; run.y += w.y; run.z += w.z; run.w += w.w; }
+        all.x += w.x; all.y += w.y; all.z += w.z; all.w += w.w;
+    }
+    if (g == 0) reinterpret_cast<int4 *>(acc)[q] = all;
+    if (held) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (t0 + k < t1) rows[(size_t)(t0 + k) * 64] = run;
             run.x += v[k].x; run.y += v[k].y; run.z += v[k].z; run.w += v[k].w;
+        }
+    } else {
+        for (int tb = t0; tb < t1; tb += 8) { // eight rows at a time: loads together, then the stores
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tb + k < t1 ? rows[(size_t)(tb + k) * 64] : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (tb + k < t1) rows[(size_t)(tb + k) * 64] = run;
+                run.x += v[k].x; run.y += v[k].y; run.z += v[k].z; run.w += v[k].w;
+            }
         }
     }
 }
@@ -1161,11 +1182,11 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
     }
     if (g.small) {
-        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
+        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
                            n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(1), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
+        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
                            shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
