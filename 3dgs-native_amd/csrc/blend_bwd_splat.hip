@@ -173,14 +173,16 @@ __device__ __forceinline__ float power_ref_order(float ca2, float cb2, float tc,
 }
 #pragma clang fp contract(fast)
 
-// Candidate chunks (of 64) requested per fill iteration on the masks path.  More chunks per memory round trip shorten the fill
-// (a quarter of a wave's life) but the ring grows with them, and its LDS is occupancy: at C3 1 / 2 / 4 chunks ran the kernel in
-// 170.0 / 177.4 / 175.1 us.
+// Candidate chunks (of 64) requested per fill iteration on the masks path: more chunks per memory round trip shorten the fill (a
+// quarter of a wave's life).  Round 2 let the ring grow with them (128 entries per chunk), and its LDS is occupancy: 1 / 2 / 4
+// chunks ran the kernel in 170.0 / 177.4 / 175.1 us at C3.  Since round 3 the ring stays at 128 entries and a requested chunk is
+// consumed only while another 64 survivors would still fit (otherwise it is requested again later -- at C3's 12 % hit rate that is
+// rare): 1 / 2 / 3 / 4 chunks 154.7 / 152.6 / 151.8 / 152.5 us at C3, 494 / 484 / - / 485 at C2i, 420 / 428 / - / 417 at C5.
 #ifndef GSR_FILL_K
-#define GSR_FILL_K 1
+#define GSR_FILL_K 4
 #endif
 constexpr int FILL_K = GSR_FILL_K;
-constexpr int QCAP = 128 * FILL_K;        // ring of compacted entries (power of two, >= 63 + 64 * FILL_K)
+constexpr int QCAP = 128;                 // ring of compacted entries (power of two, >= 63 + 64): a chunk is consumed only while it fits
 
 // USE_MASKS: the per-block hit masks the forward wrote (GsrBinning.block_masks) replace the compaction's own test.  They are
 // per 8x4 block; an 8x8 block ORs the bits of its two halves, a 4x4 block keeps its own (finer) test.
@@ -314,15 +316,18 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                         mvs[j] = (int)block_masks[idx];
                     }
                 }
+                int used = 0;
 #pragma unroll
                 for (int j = 0; j < FILL_K; ++j) {
+                    if (j > 0 && qn > QCAP - 64) break; // (wave-uniform) the ring may not take another 64: the chunk is requested again later
                     const int idx = cursor - 1 - (j * 64 + lane);
                     const bool hit = idx >= start && ((mvs[j] >> mask_shift) & mask_bits) != 0;
                     const unsigned long long m = __ballot(hit);
                     if (hit) s_ring[(head + qn + __popcll(m & lt_mask)) & (QCAP - 1)] = make_int2(ids[j], idx);
                     qn += __popcll(m);
+                    used = j + 1;
                 }
-                cursor = max(start, cursor - 64 * FILL_K);
+                cursor = max(start, cursor - 64 * used);
                 continue;
             }
             const int lo = max(start, cursor - 64);
