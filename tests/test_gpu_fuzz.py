@@ -1,6 +1,6 @@
 """Seeded sweep of small random configurations through the whole forward + backward parity comparison (HIP vs oracle):
 ragged sizes, every SH degree, both matrix conventions, tiny and huge splats, near-plane crossings, duplicate depths,
-transparent and opaque Gaussians.  GSR_FUZZ_CASES sets the number of cases (default 32 -- seed 27, N = 1 with one big off-centre splat, once read SH rows past the array; the last round-1 sweep ran 20 000 cases, all passing)."""
+transparent and opaque Gaussians.  GSR_FUZZ_CASES sets the number of cases (default 32 -- seed 27, N = 1 with one big off-centre splat, once read SH rows past the array; the last round-1 sweep ran 20 000 cases, all passing; so did the sweep on round 3's last build, 20 000 cases with the default paths and 4 000 under GSR_DEBUG=2016, every alternative path)."""
 import os
 
 import numpy as np
