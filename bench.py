@@ -290,7 +290,10 @@ def main():
         elapsed = float(tt.item())
 
     if world > 1:
-        exchange_report = measure_exchange(gsr, dist, torch, args, world, N, means, step, exchange)
+        try:
+            exchange_report = measure_exchange(gsr, dist, torch, args, world, N, means, step, exchange)
+        except Exception as e:      # the line with `value` (already measured) must still go out; every rank runs the same code
+            exchange_report = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * vps * W * H / (elapsed / args.steps) / 1e6
