@@ -136,6 +136,25 @@ if "--lpt" in sys.argv:
     for x in range(8):
         tab2[x::8] = np.arange(x * per, (x + 1) * per)
     timed(tab2, "bands, natural order (= GSR_BWD_XCD=1 through the table)")
+    # staggered starts: the first round of a band (1024 wave slots per XCD) ends all at once when it is uniformly heavy (a dip to 22
+    # of 32 resident waves per CU at 40 % of the span): every second / fourth slot of the first round takes a LIGHT block instead
+    for every in (2, 4):
+        tabs = np.empty(nblk, np.int64)
+        for x in range(8):
+            band = np.arange(x * per, (x + 1) * per)
+            o = list(band[np.argsort(-life[band], kind="stable")])
+            first = min(1024, len(o))
+            n_light = first // every
+            heavy, light = o[:len(o) - n_light], o[len(o) - n_light:][::-1]
+            seq, hi, li = [], 0, 0
+            for k in range(first):
+                if k % every == every - 1 and li < len(light):
+                    seq.append(light[li]); li += 1
+                else:
+                    seq.append(heavy[hi]); hi += 1
+            seq += heavy[hi:] + light[li:]
+            tabs[x::8] = np.asarray(seq)
+        timed(tabs, f"longest first inside each band, every {every}th slot of the first round a light block")
     # coarse classes only (what a cheap on-device binning could deliver): 8 classes by life
     cls = np.minimum(7, (8 * np.argsort(np.argsort(-life)) // nblk))
     tab3 = np.empty(nblk, np.int64)
