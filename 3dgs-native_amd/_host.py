@@ -101,3 +101,17 @@ def ptr(t):
 
 def stream_ptr(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def version_of(t):
+    """torch's in-place write counter of a tensor (None for anything else): tags that let backward() reuse state the forward
+    derived from an array record it, so a caller's in-place write between the two calls is seen."""
+    return t._version if isinstance(t, torch.Tensor) else None
+
+
+def written_in_place(*tensors):
+    """Tell torch that the library has written into these tensors through raw pointers (Adam, opacity reset ...): bumps their
+    version counters exactly as a torch in-place op would, so stale forward state tagged with the old versions is dropped."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor):
+            torch.autograd.graph.increment_version(t)

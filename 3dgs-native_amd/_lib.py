@@ -141,10 +141,17 @@ def check(code):
 
 
 def stage_timing(enable, max_steps=256, every=1):
-    """Record per-stage HIP events on one forward/backward pair in `every` (event records are not free)."""
+    """Record per-stage HIP events on one forward/backward pair in `every` (event records are not free).  every = 0 creates the
+    events but records nothing until stage_sampling(k >= 1): a benchmark allocates them before its warm-up and switches them on
+    only for steps it does not time."""
     check(lib().gsr_stage_timing(1 if enable else 0, int(max_steps)))
     if enable:
         check(lib().gsr_stage_sampling(int(every)))
+
+
+def stage_sampling(every):
+    """0 = pause the recording (events stay allocated), k >= 1 = record one forward/backward pair in k."""
+    check(lib().gsr_stage_sampling(int(every)))
 
 
 def stage_times():

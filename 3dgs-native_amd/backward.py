@@ -28,10 +28,9 @@ def _zeros_cov3d(n, dev):
     (N, 6) zero tensor (`.view(-1)`, `.numpy()`, strides as the reference's array) that is cleared ONCE per (N, device) and
     then SHARED by every later call with that N: it is meant to be read.  A caller that writes into it changes what later
     calls return; `dL_dcov3D.clone()` gives a private copy."""
-    z = _ZERO.get((n, dev.index))
-    if z is None:
-        _ZERO.clear()                      # one size at a time: a trainer's N changes only at densification
-        z = _ZERO[(n, dev.index)] = torch.zeros((n, 6), dtype=torch.float32, device=dev)
+    z = _ZERO.get(dev.index)               # one entry per device, replaced when that device's N changes (a trainer's N changes
+    if z is None or z.shape[0] != n:       # only at densification; a process that alternates two GPUs keeps both)
+        z = _ZERO[dev.index] = torch.zeros((n, 6), dtype=torch.float32, device=dev)
     return z
 
 
@@ -49,6 +48,8 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     if sh_gradient not in ("dense", "factored", "both"):
         raise ValueError("sh_gradient must be 'dense', 'factored' or 'both'")
     factored = sh_gradient == "factored"
+    from . import forward as _forward
+    _forward._backward_seen = True     # from now on this process's forwards pre-clear the backward workspace (forward.PRECLEAR_BACKWARD)
     L = _lib.lib()
     dev = _host.device_of(means3D, dL_dpixels, shs, radii)
     H, W = int(image_height), int(image_width)
@@ -71,6 +72,14 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
         rgb = geom_buffer.get("rgb") if rgb is None else rgb
         clamped = geom_buffer.get("clamped_state") if clamped is None else clamped
     rec_tag = getattr(means2D, "_gsr_records", None)     # set by render_gaussians on its points_xy_image tensor
+    if rec_tag is not None:
+        # the packed records are an image of means2D / conic_opacity / rgb as the forward wrote them: they stand in for the three
+        # arrays only if the caller hands back those very tensors, unwritten since (the reference re-reads the arrays)
+        src = rec_tag[3]
+        given3 = {"means2D": means2D, "conic_opacity": conic_opacity, "rgb": rgb}
+        fresh = all(src[k][0]() is given3[k] and _host.version_of(given3[k]) == src[k][1] for k in given3)
+        rec_tag = rec_tag[:3] if fresh else None
+    backward.last_call_used_forward_records = rec_tag is not None   # for tests and debugging (the workspace generation is checked below)
     # The forward's per-entry block masks ride on its point_list tensor.  They are conservative only for THAT forward's records
     # and written only up to each tile's saturation batch, so they are honoured only when every buffer they were derived from
     # or are read against is the forward's own tensor (identity, not equality): a caller who mixes in perturbed means2D /
@@ -81,7 +90,7 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     if mask_tag is not None:
         m_t, owners, o_t = mask_tag
         given = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": means2D, "conic_opacity": conic_opacity}
-        if all(owners[k]() is given[k] for k in given):
+        if all(owners[k][0]() is given[k] and _host.version_of(given[k]) == owners[k][1] for k in given):
             masks, order = m_t, o_t      # (the block order rides with the masks: it was derived from them)
     # likewise the forward's d(colour)/d(direction) sums (GsrGeom.sh_dir_grad) ride on its clamped_state tensor: used when shs
     # and means3D are the very tensors that forward read, with the same camera position and degree -- geom_backward_kernel then
@@ -89,8 +98,9 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     sh_dir = None
     dir_tag = getattr(clamped, "_gsr_sh_dir", None)
     if dir_tag is not None:
-        d_t, sh_ref, means_ref, campos_f, deg_f = dir_tag
-        if (sh_ref() is shs and means_ref() is means3D and deg_f == int(degree) and d_t.device == dev
+        d_t, sh_ref, means_ref, campos_f, deg_f, sh_ver, means_ver = dir_tag
+        if (sh_ref() is shs and means_ref() is means3D and _host.version_of(shs) == sh_ver and _host.version_of(means3D) == means_ver
+                and deg_f == int(degree) and d_t.device == dev
                 and campos_f == tuple(float(v) for v in _host.host_f32(campos, 3))):
             sh_dir = d_t
     backward.last_call_used_forward_sh_dir = sh_dir is not None     # for tests and debugging

@@ -7,16 +7,14 @@ reference's inputs bit-for-meaning:
 
 * `nerf_camera`  -- NeRF-synthetic `transform_matrix` -> the dict train.py feeds to the rasterizer
                     (reference utils/camera_utils.py:8-89; utils/math_utils.py:8-41).
-* `load_camera` / `load_camera_from_json` / `world_to_view` / `projection_matrix` / `matrix_to_quaternion`
+* `load_camera` / `world_to_view` / `projection_matrix` / `matrix_to_quaternion`
                  -- the reference's own helper names (utils/camera_utils.py:8-106, utils/math_utils.py:8-95) over the
                     same math, for callers written against them.
 * `toy_camera`   -- the hard-coded camera of the 3-Gaussian demo (reference render.py:11-50), including
                     its quirk of passing the un-transposed `world_to_view` matrix as the view matrix
                      and degrees-as-radians FoV (tan(22.5 rad)).
 """
-import json
 import math
-import os
 
 import numpy as np
 
@@ -155,20 +153,3 @@ def load_camera(camera_info):
                 "camera_type": _CAMERA_TYPES[model],
                 "distortion_params": np.array([camera_info.get(k, 0.0) for k in _DISTORTION_KEYS], dtype=np.float32)})
     return cam
-
-
-def load_camera_from_json(input_path, camera_id=0):
-    """`cameras.json` next to `input_path` -> load_camera of the record with that id, else of the first record; None when
-    the file is missing or unreadable (reference utils/camera_utils.py:93-113)."""
-    camera_file = os.path.join(os.path.dirname(input_path), "cameras.json")
-    if not os.path.exists(camera_file):
-        print(f"Warning: No cameras.json found in {os.path.dirname(input_path)}, using default camera")
-        return None
-    try:
-        with open(camera_file, "r") as f:
-            records = json.load(f)
-        chosen = next((c for c in records if c["id"] == camera_id), records[0])
-        return load_camera(chosen)
-    except Exception as e:   # noqa: BLE001 -- the reference swallows every error here and falls back to its default camera
-        print(f"Error loading camera from cameras.json: {e}")
-        return None

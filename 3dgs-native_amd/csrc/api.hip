@@ -157,6 +157,7 @@ int timer_open(bool forward)
     if (!g_timer.on.load(std::memory_order_relaxed)) return -1;
     int &calls = forward ? g_timer.fwd_calls : g_timer.bwd_calls;
     int &step = forward ? g_timer.fwd_step : g_timer.bwd_step;
+    if (g_timer.every == 0) return -1; // paused: the events exist, nothing is recorded
     if ((calls++ % g_timer.every) != 0 || step >= g_timer.max_steps) return -1;
     return step++;
 }
@@ -337,7 +338,9 @@ size_t gsr_backward_workspace_bytes(int64_t N, int64_t, int32_t, int32_t) { retu
 size_t gsr_block_order_ints(int32_t W, int32_t H)
 {
     if (W <= 0 || H <= 0) return 0;
-    return gsr_bo_ints(((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE));
+    const int64_t tiles = (int64_t)((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE);
+    // images of more than GSR_BO_MAX_TILES tiles are never filed (gsr_internal.h): only the header (counters + the `filed` flag) is touched
+    return tiles > GSR_BO_MAX_TILES ? (size_t)GSR_BO_HEADER : gsr_bo_ints((int)tiles);
 }
 
 int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, void *geom_ws, size_t geom_ws_bytes,
@@ -421,6 +424,11 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
         HIP_TRY(hipMemsetAsync(image->inv_depth, 0, P * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(image->final_T, 0, P * sizeof(float), s));
         HIP_TRY(hipMemsetAsync(image->n_contrib, 0, P * sizeof(int32_t), s));
+        // the accumulator clear of GsrBinning.backward_ws is promised whenever the workspace is handed over, blend or no blend
+        if (binning->backward_ws && N > 0) {
+            if (!gsr_aligned16(binning->backward_ws)) return GSR_E_ALIGN;
+            HIP_TRY(hipMemsetAsync(carve_bwd(binning->backward_ws, N).acc, 0, sizeof(GradRec) * (size_t)N, s));
+        }
         return GSR_OK;
     }
     if (!geom_ok(geom) || !binning->point_list) return GSR_E_NULL;
@@ -613,9 +621,10 @@ int gsr_stage_timing(int enable, int max_steps)
 
 int gsr_stage_sampling(int every)
 {
-    if (every < 1) return GSR_E_DIMS;
+    if (every < 0) return GSR_E_DIMS;
     std::lock_guard<std::mutex> lk(g_timer_mu);
-    g_timer.every = every;
+    g_timer.every = every; // 0 = paused (events stay allocated), k >= 1 = one forward/backward pair in k
+    g_timer.fwd_calls = g_timer.bwd_calls = 0;
     return GSR_OK;
 }
 

@@ -199,9 +199,24 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         na = rp[0]; nb = rp[1];
         ncd = *reinterpret_cast<const float2 *>(rp + 2);
     }
+#ifdef GSR_FWD_COUNT_INLINE
+    // block filing without re-reading the masks: per 8x4 block of this wave (A = rows 0-3 = lanes 0-31, B = rows 4-7), the mask
+    // hits of every batch walked so far (scalar: two more ballots per 64 entries of the list build) and their value at the end of
+    // the last batch in which one of the block's pixels took a contribution
+    int cum_a = 0, cum_b = 0, kept_a = 0, kept_b = 0;
+    const int bit_a = 1 << ((wv >> 1) * 4 + (wv & 1)), bit_b = bit_a << 2;
+#endif
+#ifdef GSR_FWD_PRIO
+    int bidx = 0;
+#endif
     for (int base = start; base < end; base += BATCH) {
         if (__syncthreads_and(done)) break; // whole tile saturated (also fences LDS reuse)
         TL(0) // top barrier (first time: launch -> here)
+#ifdef GSR_FWD_PRIO
+        // a wave deep in its list is one of the long-lived ones that decide when the kernel ends: it goes first
+        { const int pr = bidx >> GSR_FWD_PRIO; ++bidx;
+          if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr >= 3) __builtin_amdgcn_s_setprio(3); }
+#endif
 
         const int cnt = min(BATCH, end - base);
 #ifdef GSR_TIMELINE
@@ -268,6 +283,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             const int mv = (g + lane < cnt) ? (int)s_mask[g + lane] : 0;
             const bool hit = (mv & my_bits) != 0;
             const unsigned long long bits = __ballot(hit);
+#ifdef GSR_FWD_COUNT_INLINE
+            cum_a += __popcll(__ballot((mv & bit_a) != 0));
+            cum_b += __popcll(__ballot((mv & bit_b) != 0));
+#endif
             if (hit) s_list[wv][n + __popcll(bits & lt_mask)] = (uint16_t)((g + lane) * REC_BYTES);
             n += __popcll(bits);
         }
@@ -336,6 +355,13 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         // n_contrib = 1-based list position of the last contributing entry: offset / 48 by multiply-shift (exact below 2^16)
         if (last_off >= 0) last = base - start + (int)(((unsigned)last_off * 43691u) >> 21) + 1;
         done = pixf_x == PARKED_X;
+#ifdef GSR_FWD_COUNT_INLINE
+        {
+            const unsigned long long took = __ballot(last_off >= 0);
+            if ((unsigned)took) kept_a = cum_a;
+            if ((unsigned)(took >> 32)) kept_b = cum_b;
+        }
+#endif
         TL(5) // list walk
     }
 
@@ -348,7 +374,18 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         image[3 * px + 2] = cb + T * bg2;
         inv_depth[px] = cd;
     }
+#ifdef GSR_FWD_COUNT_INLINE
+    if (block_order && (lane & 31) == 0) {
+        const int hits = lane ? kept_b : kept_a;
+        const int blk = (wv >> 1) * 4 + (wv & 1) + ((lane >> 5) << 1);
+        const int tpb = (n_tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS, band = tile / tpb;
+        const int q = (band * GSR_BO_CLASSES + gsr_bo_class(hits)) * GSR_BO_SHARDS + ((tile - band * tpb) & (GSR_BO_SHARDS - 1));
+        const int pos = atomicAdd(&block_order[q], 1);
+        if (pos < bo_cap) block_order[GSR_BO_HEADER + (size_t)q * bo_cap + pos] = tile * 8 + blk;
+    }
+#else
     if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, tile, start, last);
+#endif
     TL(6)
     TL_FLUSH
 }
@@ -383,6 +420,11 @@ hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, cons
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
+    // the clear is part of the call's contract (gsr.h GsrBinning.backward_ws): when this launch cannot host the spare workgroups
+    // (the XCD map derives the tile from gridDim.x) it is a memset in front of the kernel instead
+    if (clear && gsr_fwd_xcd_map) {
+        if (hipError_t e = hipMemsetAsync(clear, 0, clear_bytes, s)) return e;
+    }
     const long long clear_n4 = (clear && !gsr_fwd_xcd_map) ? (long long)(clear_bytes / 16) : 0;
     const int clear_wgs = (int)std::min<long long>(2048, (clear_n4 + 255) / 256);
     const int grid = (gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles) + clear_wgs;

@@ -141,6 +141,7 @@ def reset_opacities(opacities, max_opacity=0.01):
     dev = opacities.device
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().gsr_reset_opacities(int(opacities.numel()), float(max_opacity), _host.ptr(opacities), _host.stream_ptr(dev)))
+    _host.written_in_place(opacities)
 
 
 def init_gaussian_params(num_points, init_scale=0.1, device="cuda"):

@@ -15,7 +15,10 @@ from .config import TILE_M, TILE_N
 # Training use (the default): the forward blend kernel's spare workgroups clear the accumulators of the backward workspace while
 # that kernel drains, so the backward() that follows does not start with a 64-byte-per-Gaussian clear of its own.  A render-only
 # user can switch it off (it allocates the backward's scratch): forward.PRECLEAR_BACKWARD = False.
+# It is lazy: nothing is allocated or cleared for the backward until this process has called backward() once (a render-only
+# process never pays for it); the first training step's backward clears for itself.
 PRECLEAR_BACKWARD = not bool(int(os.environ.get("GSR_NO_PRECLEAR", "0")))
+_backward_seen = False          # set by backward.backward()
 _NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))   # A/B switch: backward reads the SH rows itself (same results)
 
 
@@ -76,7 +79,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         # the backward blend's blocks filed by cost, heaviest first (GsrBinning.block_order): filled by the forward blend from the masks
         block_order = e((int(L.gsr_block_order_ints(W, H)),), i32)
         bwd_ws = None
-        if PRECLEAR_BACKWARD and N > 0 and D > 0:
+        if PRECLEAR_BACKWARD and _backward_seen and N > 0 and D > 0:
             bwd_ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
             _host.workspace_written(bwd_ws)
         binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks), _host.ptr(block_order),
@@ -88,7 +91,9 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     # the tag rides on the means2D tensor (the reference's callers re-pack the dicts by hand, train.py:986-1000)
     # and is honoured only while no later forward has overwritten that workspace.
     if N > 0:
-        xy._gsr_records = _host.tag_records(gws, N)
+        # (the records are an image of these three arrays as this call wrote them: identity AND version are checked)
+        xy._gsr_records = _host.tag_records(gws, N) + ({"means2D": (weakref.ref(xy), xy._version), "conic_opacity": (weakref.ref(conic_opacity), conic_opacity._version),
+                                                        "rgb": (weakref.ref(rgb), rgb._version)},)
         # likewise the block masks ride on the point_list tensor (their own allocation, alive as long as it is): a caller
         # that hands backward() this very tensor gets the mask-driven compaction, anyone else the self-contained one
         # -- and only together with the other buffers of this call (backward() checks identity): the masks describe these
@@ -96,9 +101,12 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         if sh_dir is not None:
             # the direction derivatives ride on clamped_state (which backward() receives as `clamped`), valid for these very
             # sh / means3D tensors, this camera position and this degree
-            clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(float(v) for v in cam.campos), int(degree))
+            # -- and only while neither has been written in place since (torch's version counters; the library's own in-place
+            # writers, Adam and the opacity reset, bump them too: _host.written_in_place)
+            clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(float(v) for v in cam.campos), int(degree),
+                                         sh._version, means3D._version)
         owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
-        point_list._gsr_block_masks = (block_masks, {k: weakref.ref(v) for k, v in owners.items()}, block_order)
+        point_list._gsr_block_masks = (block_masks, {k: (weakref.ref(v), v._version) for k, v in owners.items()}, block_order)
         if bwd_ws is not None:      # "this backward workspace has clean accumulators as of this generation" (backward() checks)
             point_list._gsr_cleared_ws = _host.tag_records(bwd_ws, N)
     return image, depth_image, {

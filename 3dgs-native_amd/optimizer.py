@@ -64,3 +64,6 @@ def adam_update(params, grads, m, v, lrs=None, beta1=0.9, beta2=0.999, epsilon=1
             ptrs = (C.c_void_p * len(rows))(*[r.data_ptr() for r in rows])
             scale = float(sh_scale) if sh_scale is not None else 1.0 / len(rows)
             _lib.check(L.gsr_adam_update_views(C.byref(a), int(sh_degree), len(rows), ptrs, scale, _host.stream_ptr(dev)))
+    # the kernel wrote through raw pointers: let torch's version counters say so (a backward() that is handed these tensors with a
+    # forward's buffers from BEFORE this step must not reuse what that forward derived from the old values)
+    _host.written_in_place(*[d[k] for k in GROUPS for d in (params, m, v)])

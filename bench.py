@@ -19,7 +19,8 @@ locally (3dgs-native_amd/dist.py; `--dense-exchange` all-reduces all 59 instead)
 
 The JSON line also carries
   roofline     -- the dominant kernel (longest average stage) measured with HIP events recorded by the
-                  library on the launch stream during the timed region, priced against the 8 TB/s HBM
+                  library on the launch stream in a second, untimed loop of 20 steps right after the timed
+                  region (so `value` pays for no stage event), priced against the 8 TB/s HBM
                   peak with the algorithmic bytes of DESIGN.md; `pipeline` = the same for the whole
                   forward+backward byte budget B = 340 N + 596 Nv + 128 D + 16 Tn + 44 P;
   cpu_baseline -- the CPU oracle (a single-thread C restatement of the reference kernels; Warp's CPU
@@ -73,12 +74,25 @@ def roofline_valu(stage, counters, avg_ms):
             "frac_at_measured_issue_prices": round(insts * AVG_ISSUE_CYCLES_MEASURED.get(stage, 2.3) / have, 4), "avg_ms": round(avg_ms, 4)}
 
 
-def stage_bytes(N, Nv, D, P, Tn):
+def depth_passes_needed(depths, radii):
+    """The depth sort's pass count for this frame, as the library's device-side plan derives it (gsr_internal.h gsr_depth_plan):
+    8-bit passes over the range of the visible Gaussians' depth bits above their minimum (low byte of the minimum cleared)."""
+    vis = depths[radii > 0]
+    if vis.numel() == 0:
+        return 1
+    bits = vis.view(__import__("torch").int32)         # positive floats order like their bit patterns
+    lo, hi = int(bits.min().item()), int(bits.max().item())
+    rng = hi - (lo & ~255) + 1
+    return max(1, (max(1, rng).bit_length() + 7) // 8)
+
+
+def stage_bytes(N, Nv, D, P, Tn, depth_passes=4):
     """Algorithmic HBM bytes per launch of each timed stage.  The per-unit figures are SURVEY.md section 8(d)'s
     (compulsory traffic: every input read once, every output written once, every list entry read once per
     tile) for the stages the reference has, and the same counting rule for the stages of our own binning
     design, priced from the item widths and pass counts the library really uses (api.hip): depth items are
-    8 bytes (4 passes: histogram read + scatter read + write); tile items are 4 bytes when tile bits + id bits <= 32 (C3: 12 + 20),
+    8 bytes; the first of the frame's `depth_passes` active passes reads all N items (its histogram read is the scan stage's) and
+    writes the Nv visible ones, every later pass reads the Nv survivors twice (histogram, scatter) and writes them once; tile items are 4 bytes when tile bits + id bits <= 32 (C3: 12 + 20),
     else 8, ceil(tile bits / 8) passes, the first of which has no histogram read (the expansion leaves its histograms) and the last
     of which writes the 4-byte point_list instead of items; the depth-order offsets are one read of the sorted counts."""
     tb = max(1, int(np.ceil(np.log2(max(2, Tn)))))
@@ -88,7 +102,7 @@ def stage_bytes(N, Nv, D, P, Tn):
     return {
         "preprocess": 44 * N + 192 * Nv + 8 * N + 76 * Nv,
         "scan": 8 * N + 8 * N,             # + the first depth pass's histogram read (made in the scan's launch)
-        "depth_sort": 4 * 24 * N - 8 * N,
+        "depth_sort": 8 * N + 8 * Nv + (depth_passes - 1) * 24 * Nv,
         "depth_scan": 4 * N,
         "expand": 16 * Nv + ib * D,
         "tile_sort": ((ib + 4) * D if npass == 1 else 2 * ib * D + (npass - 2) * 3 * ib * D + (2 * ib + 4) * D) + 8 * Tn,
@@ -152,7 +166,8 @@ def main():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5", "C0", "C2i"], help="C3 is the headline workload; C0 / C2i are the "
                     "reference trainer's initial point set (5 000 / 100 000 Gaussians of scale 0.1), not headline configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
+    ap.add_argument("--no-stage-events", action="store_true", help="skip the second, untimed loop that records per-stage HIP events "
+                    "(the timed region never carries them)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend; nccl is RCCL (default). gloo + "
                     "--single-device rehearse the N>1 path on a one-GPU box")
     ap.add_argument("--views-per-step", type=int, default=1, help="N=1 only, not the headline workload: render this many views per "
@@ -160,6 +175,9 @@ def main():
     ap.add_argument("--dense-exchange", action="store_true", help="N>1: all-reduce the full 59-float arena instead of the factored "
                     "exchange (11 floats all-reduced + 3 all-gathered per Gaussian, SH gradient rebuilt locally)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--preheat-steps", type=int, default=100, help="untimed steps before the --warmup steps, so that a short warm-up "
+                    "still starts from steady clocks (about 60 ms of load at C3)")
+    ap.add_argument("--dump-steps", default=None, help="write every timed step's device time (ms, rank 0) to this file, one per line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -253,23 +271,42 @@ def main():
                 main.wait_stream(st_)
             return last
 
-    for _ in range(args.warmup):
-        buf, grads = step()
+    # Everything the measurement itself needs exists BEFORE the warm-up: the library's per-stage events (allocated, paused), one
+    # HIP event per step boundary (torch creates an event at its first record, so each is recorded once here), the workload's
+    # D / visible count (one untimed step + two readbacks), and the interpreter's collector run and switched off (as `timeit`
+    # does: a generation-2 pass stalls the launch thread for ~1 ms every ~150 steps).  Between the last warm-up step and the timed
+    # region there is only the synchronize (+ barrier) the protocol asks for, and no stage event is recorded inside the region.
+    use_events = not args.no_stage_events
+    STAGE_STEPS = 20
+    if use_events:
+        gsr._lib.stage_timing(True, STAGE_STEPS, every=0)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for m in marks:
+        m.record()
+    buf, grads = step()
     torch.cuda.synchronize()
     D = int(buf["point_list"].shape[0])
     Nv = int((buf["radii"] > 0).sum().item())
-
-    use_events = not args.no_stage_events
-    if use_events:
-        # one step in ten (in five for short runs) carries the per-stage HIP events: 14 records cost ~6 % of a C3 step, so the
-        # sampled steps are the p90 of step_ms and the wall-clock mean carries ~0.6 % of measurement
-        gsr._lib.stage_timing(True, args.steps, every=10 if args.steps >= 20 else 5 if args.steps >= 10 else 1)
+    depth_passes = depth_passes_needed(buf["depths"].view(-1), buf["radii"].view(-1))
+    del buf, grads
+    import gc
+    gc.collect()
+    gc.disable()
+    # Pre-heat: after the GPU has idled for more than about a millisecond (here: the scene build, the readbacks above) it needs
+    # 10-20 ms of load to come back to its steady clocks -- the first ~20 steps run at 0.63-0.65 ms, later ones at 0.61
+    # (tools/ramp_probe.py, gpurun_out/r04_b/ramp_probe.txt) -- which a 5-step warm-up (3 ms) does not cover.  So
+    # --preheat-steps untimed steps (a fixed count: every rank runs the same number of collectives) precede the W warm-up steps
+    # asked for, back to back with them, and the line reports them (`preheat_steps`).
+    for _ in range(max(0, args.preheat_steps)):
+        step()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     # one HIP event per step boundary on the launch stream (torch's current stream IS the stream handed to the library):
     # per-step device times for the median / p10 / p90; `ms_per_step` stays the wall-clock mean of the whole region
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for k in range(args.steps):
@@ -280,8 +317,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    # the per-stage table comes from a SECOND, untimed loop with the library's stage events on every step
     stages, nrec = ({}, 0)
     if use_events:
+        gsr._lib.stage_sampling(1)
+        for _ in range(STAGE_STEPS):
+            step()
+        torch.cuda.synchronize()
         stages, nrec = gsr._lib.stage_times()
         gsr._lib.stage_timing(False)
     if world > 1:
@@ -298,11 +341,14 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * vps * W * H / (elapsed / args.steps) / 1e6
     per_step = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])   # this rank's device time per step
+    if args.dump_steps and rank == 0:
+        np.savetxt(args.dump_steps, per_step, fmt="%.4f")
     backend_name = "RCCL" if args.backend == "nccl" else "gloo (host memory" + (", every rank on cuda:0: a rehearsal" if args.single_device else "") + ")"
 
     out = {
         "metric": "Mpixels/s forward+backward at 800x800, 1M Gaussians" if args.config == "C3" else f"Mpixels/s forward+backward ({args.config})",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "preheat_steps": max(0, args.preheat_steps),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {'reference initial point set (scale ' + str(cfg['init_scale']) + ')' if 'init_scale' in cfg else 'synthetic'} {W}x{H}, {N} Gaussians, SH degree 3, seed {cfg['seed']}, forward+backward, "
@@ -312,7 +358,8 @@ def main():
                                                                                         f", {backend_name} all-reduce of 11 floats + all-gather of 3 floats per Gaussian, SH gradient rebuilt per rank") if world > 1 else "")},
         "step_ms": {"median": round(float(np.median(per_step)), 4), "p10": round(float(np.percentile(per_step, 10)), 4),
                     "p90": round(float(np.percentile(per_step, 90)), 4), "min": round(float(per_step.min()), 4),
-                    "max": round(float(per_step.max()), 4), "n": int(args.steps),
+                    "max": round(float(per_step.max()), 4), "argmax": int(per_step.argmax()), "n": int(args.steps),
+                    "first": [round(float(x), 4) for x in per_step[:8]],
                     "how": "HIP events on the launch stream between consecutive steps (rank 0); ms_per_step is the wall-clock mean"},
     }
 
@@ -321,7 +368,7 @@ def main():
     if rank == 0:
         P, Tn = W * H, ((W + 15) // 16) * ((H + 15) // 16)
         if stages and nrec > 0:
-            sb = stage_bytes(N, Nv, D, P, Tn)
+            sb = stage_bytes(N, Nv, D, P, Tn, depth_passes)
             timed = {k: v for k, v in stages.items() if k in sb}
             dom = max(timed, key=timed.get)
             dur_s = timed[dom] * 1e-3

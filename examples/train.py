@@ -49,9 +49,9 @@ import torch  # noqa: E402
 gsr = importlib.import_module("3dgs-native_amd")
 
 
-def load_nerf(path, max_views):
+def load_nerf(path, max_views, split="train"):
     from PIL import Image
-    with open(os.path.join(path, "transforms_train.json")) as f:
+    with open(os.path.join(path, f"transforms_{split}.json")) as f:
         tf = json.load(f)
     cams, targets = [], []
     for fr in tf["frames"][:max_views]:
@@ -59,6 +59,64 @@ def load_nerf(path, max_views):
         targets.append(img[:, :, :3].copy())
         cams.append(gsr.cameras.nerf_camera(fr["transform_matrix"], img.shape[1], img.shape[0], tf["camera_angle_x"]))
     return cams, targets
+
+
+def render_view(P, c, bg):
+    return gsr.render_gaussians(background=bg, means3D=P["positions"], opacity=P["opacities"], scales=P["scales"], rotations=P["rotations"],
+                                viewmatrix=c["world_to_camera"], projmatrix=c["full_proj_matrix"], tan_fovx=c["tan_fovx"], tan_fovy=c["tan_fovy"],
+                                image_height=c["height"], image_width=c["width"], sh=P["shs"], degree=3, campos=c["camera_center"])[0]
+
+
+def score_views(P, cams, targets, bg):
+    """Per-view mean L1 and PSNR (10 log10(1 / MSE), colours in [0, 1]) of the current model; the images come back too."""
+    rows, images = [], []
+    for c, t in zip(cams, targets):
+        img = render_view(P, c, bg).reshape(t.shape)
+        d = img - t
+        mse = float((d * d).mean().item())
+        rows.append({"l1": float(d.abs().mean().item()), "psnr": (10.0 * np.log10(1.0 / mse)) if mse > 0 else float("inf")})
+        images.append(img)
+    return rows, images
+
+
+def finish(args, model, cams, targets, bg, loss_hist, density_log, wall, dev):
+    """The run record: parameters finite, loss curve, point count after every density-control call, timing, per-view scores, PNGs."""
+    from PIL import Image
+    P = model.params
+    finite = {k: bool(torch.isfinite(P[k]).all().item()) for k in gsr.optimizer.GROUPS}
+    rows, images = score_views(P, cams, targets, bg)
+    summary = {"iterations": args.iterations, "wall_s": round(wall, 3), "iterations_per_s": round(args.iterations / wall, 1) if wall > 0 else None,
+               "points_start": density_log[0]["points"], "points_final": model.num_points, "density_control_calls": len(density_log) - 1,
+               "parameters_finite": finite, "train_views": rows, "train_l1_mean": float(np.mean([r["l1"] for r in rows])),
+               "train_psnr_mean": float(np.mean([r["psnr"] for r in rows]))}
+    if args.holdout and args.dataset:
+        split, _, k = args.holdout.partition(":")
+        hc, ht = load_nerf(args.dataset, int(k or 8), split)
+        hrows, _ = score_views(P, hc, [torch.as_tensor(t).to(dev) for t in ht], bg)
+        summary.update({"holdout": args.holdout, "holdout_views": hrows, "holdout_l1_mean": float(np.mean([r["l1"] for r in hrows])),
+                        "holdout_psnr_mean": float(np.mean([r["psnr"] for r in hrows]))})
+    print(f"trained {args.iterations} iterations in {wall:.2f} s ({summary['iterations_per_s']} it/s); {summary['points_start']} -> "
+          f"{model.num_points} points; train L1 {summary['train_l1_mean']:.5f} PSNR {summary['train_psnr_mean']:.2f} dB"
+          + (f"; holdout PSNR {summary['holdout_psnr_mean']:.2f} dB" if "holdout_psnr_mean" in summary else "")
+          + f"; parameters finite: {all(finite.values())}", flush=True)
+    if args.log:
+        os.makedirs(os.path.dirname(os.path.abspath(args.log)), exist_ok=True)
+        curve = loss_hist[:args.iterations].cpu().numpy()
+        with open(args.log, "w") as f:
+            f.write(json.dumps({"record": "arguments", **{k: v for k, v in vars(args).items()}}) + "\n")
+            for d in density_log:
+                f.write(json.dumps({"record": "density_control", **d}) + "\n")
+            for i in range(0, len(curve), 100):               # every iteration's loss, 100 per line
+                f.write(json.dumps({"record": "loss", "from_iteration": i, "l1": [round(float(x), 6) for x in curve[i:i + 100]]}) + "\n")
+            f.write(json.dumps({"record": "summary", **summary}) + "\n")
+    if args.eval_dir:
+        os.makedirs(args.eval_dir, exist_ok=True)
+        to8 = lambda x: (x.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).cpu().numpy()
+        for k in range(min(args.eval_views, len(images))):
+            r8, t8 = to8(images[k]), to8(targets[k].reshape(images[k].shape))
+            Image.fromarray(r8).save(os.path.join(args.eval_dir, f"render_{k}.png"))
+            Image.fromarray(t8).save(os.path.join(args.eval_dir, f"target_{k}.png"))
+            Image.fromarray(np.concatenate([r8, t8], axis=1)).save(os.path.join(args.eval_dir, f"pair_{k}.png"))
 
 
 def main():
@@ -82,6 +140,13 @@ def main():
     ap.add_argument("--dense-sh", action="store_true", help="materialise the 48-float SH gradient (backward's dense return, one "
                     "59-float all-reduce when N > 1) instead of forming it inside the Adam update from the view payloads")
     ap.add_argument("--output", default=None, help="directory for point_cloud/iteration_N/point_cloud.ply")
+    ap.add_argument("--print-interval", type=int, default=10, help="iterations between loss lines (each one reads the loss back: a sync)")
+    ap.add_argument("--log", default=None, help="JSONL run record: one line per density-control call, the per-iteration loss curve, "
+                    "and a closing summary (wall time, iterations/s, per-view L1 / PSNR)")
+    ap.add_argument("--eval-dir", default=None, help="after training, write render_<k>.png / target_<k>.png / pair_<k>.png for --eval-views")
+    ap.add_argument("--eval-views", type=int, default=1, help="how many of the training views --eval-dir renders to PNG")
+    ap.add_argument("--holdout", default=None, help="NeRF-synthetic split to score after training without training on it, e.g. "
+                    "'test:8' = the first 8 frames of transforms_test.json (needs --dataset)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +193,11 @@ def main():
                 "opacity_reset_interval": args.opacity_reset_interval, "max_allowed_prune_ratio": 1.0, "background_color": [0.0, 0.0, 0.0]})
     sched = {k: gsr.scheduler.LRScheduler(lr) for k, lr in gsr.optimizer.DEFAULT_LR.items()}
     rng = np.random.default_rng(0)                                          # same stream on every rank -> same view batch
+    loss_hist = torch.zeros(max(1, args.iterations), device=dev)            # the loss curve stays on the device until the end
+    density_log = [{"iteration": -1, "points": model.num_points}]
+    import time
+    torch.cuda.synchronize(dev)
+    t_start = time.perf_counter()
     for it in range(args.iterations):
         P, M, V, n = model.params, model.adam_m, model.adam_v, model.num_points
         batch = rng.choice(len(cams), size=args.views_per_step, replace=False)
@@ -178,14 +248,23 @@ def main():
         lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}
         model.grads = gsr.optimizer.grads_from_backward(grads)              # train.py:1047-1051
         gsr.optimizer.adam_update(P, model.grads, M, V, lrs, iteration=it, sh_views=sh_views, sh_degree=3, sh_scale=sh_scale)
+        loss_hist[it] = loss_acc[0] / max(1, len(mine))
         log = model.densification_and_pruning(it)                           # train.py:1060
+        if log["cloned"] or log["split"] or log["pruned"] or log["opacity_reset"] or log["prune_skipped"]:
+            density_log.append({"iteration": it, "cloned": log["cloned"], "split": log["split"], "split_removed": log["split_removed"],
+                                "pruned": log["pruned"], "prune_skipped": log["prune_skipped"], "opacity_reset": log["opacity_reset"],
+                                "points": model.num_points})
         if rank == 0 and (log["cloned"] or log["split"] or log["pruned"] or log["opacity_reset"]):
             print(f"iter {it:5d}  densify: +{log['cloned']} cloned, {log['split']} split, -{log['pruned']} pruned"
                   f"{', opacity reset' if log['opacity_reset'] else ''} -> {model.num_points} points")
         if rank == 0 and args.output and (it % args.save_interval == 0 or it == args.iterations - 1):
             gsr.point_cloud.save_ply(model.params, os.path.join(args.output, "point_cloud", f"iteration_{it}", "point_cloud.ply"), model.num_points)
-        if rank == 0 and (it % 10 == 0 or it == args.iterations - 1):
-            print(f"iter {it:5d}  loss {float(loss_acc.item()) / max(1, len(mine)):.6f}")
+        if rank == 0 and (it % args.print_interval == 0 or it == args.iterations - 1):
+            print(f"iter {it:5d}  loss {float(loss_acc.item()) / max(1, len(mine)):.6f}", flush=True)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t_start
+    if rank == 0:
+        finish(args, model, cams, targets, bg, loss_hist, density_log, wall, dev)
 
 
 if __name__ == "__main__":

@@ -129,7 +129,10 @@ typedef struct GsrBinning {
     void *backward_ws;    /* optional: the workspace the caller will give gsr_backward (>= gsr_backward_workspace_bytes).  Handed to
                              gsr_forward_render, the forward blend kernel's spare workgroups clear the accumulator records in it
                              while that kernel drains -- the 64 bytes per Gaussian gsr_backward otherwise clears in a launch of
-                             its own (12 us at 1 M Gaussians). */
+                             its own (12 us at 1 M Gaussians).  Every successful gsr_forward_render that is handed a
+                             backward_ws leaves those records zero, also when it launches no blend (D == 0) or cannot host
+                             the spare workgroups (it then clears with a memset of its own).  The size is the caller's
+                             promise: the library has no byte count to check it against. */
     int32_t backward_ws_cleared; /* gsr_backward only: non-zero = `ws` is that `backward_ws`, and nothing has written to it since the
                              gsr_forward_render that cleared it (no other gsr_backward in particular): the clear is skipped */
 } GsrBinning;
@@ -335,7 +338,8 @@ enum {
     GSR_NSTAGES
 };
 int gsr_stage_timing(int enable, int max_steps);
-int gsr_stage_sampling(int every); /* after enabling: record only one forward/backward pair in `every` (default 1) */
+int gsr_stage_sampling(int every); /* after enabling: record only one forward/backward pair in `every` (default 1); 0 = paused (the
+                                      events stay allocated and nothing is recorded until a later call with every >= 1) */
 int gsr_stage_times(float *avg_ms /* [GSR_NSTAGES] host */, int *steps /* host */);
 
 #ifdef __cplusplus

@@ -11,7 +11,14 @@
  *   gsr_backward       = gsro_render_backward_rows + cov2d / projection / sh / cov3d backward                      (backward.py:890-953, :770-888)
  * The "next"-row entry points with a C restatement (L1 loss + gradient, SSIM, depth loss, Adam) are wired too; density
  * control and the view-exchange rebuild have numpy oracles only (oracle/densify.py, tests), so those symbols exist and
- * return GSR_E_HIP ("not in the CPU library").  The workspace functions return the bytes this library really uses (the
+ * return GSR_E_HIP ("not in the CPU library").  So "same ABI" means the same SYMBOL SET and struct layouts; the same BEHAVIOUR
+ * holds for the rasterizer entry points only:
+ *   real:  gsr_abi_version, gsr_strerror, gsr_build_flags, gsr_*_workspace_bytes, gsr_forward_count, gsr_forward_render,
+ *          gsr_backward, gsr_l1_loss_grad, gsr_ssim, gsr_depth_loss, gsr_adam_update
+ *   stubs (return GSR_E_HIP, or a constant for the sizing / timing helpers):  gsr_backward_blend, gsr_backward_geom,
+ *          gsr_sh_grad_from_views, gsr_adam_update_views, gsr_densify_mark, gsr_prune_mark, gsr_split_removal_mask, gsr_mask_scan,
+ *          gsr_mask_scan_workspace_bytes, gsr_block_order_ints, gsr_clone_gaussians, gsr_split_gaussians, gsr_compact_gaussians,
+ *          gsr_reset_opacities, gsr_init_gaussians, gsr_stage_timing, gsr_stage_sampling, gsr_stage_times  The workspace functions return the bytes this library really uses (the
  * int64 sort keys live in the binning workspace; the backward needs none beyond 16 bytes). */
 #include <stdint.h>
 #include <stdlib.h>
@@ -255,7 +262,7 @@ int gsr_compact_gaussians(const GsrParams *i, const int32_t *v, const int32_t *p
 int gsr_reset_opacities(int64_t N, float m, float *o, void *s) { (void)N; (void)m; (void)o; (void)s; return GSR_E_HIP; }
 int gsr_init_gaussians(const GsrParams *o, float i, void *s) { (void)o; (void)i; (void)s; return GSR_E_HIP; }
 int gsr_stage_timing(int enable, int max_steps) { (void)enable; (void)max_steps; return GSR_OK; }
-int gsr_stage_sampling(int every) { return every < 1 ? GSR_E_DIMS : GSR_OK; }
+int gsr_stage_sampling(int every) { return every < 0 ? GSR_E_DIMS : GSR_OK; }
 int gsr_stage_times(float *avg_ms, int *steps)
 {
     if (!avg_ms || !steps) return GSR_E_NULL;

@@ -25,3 +25,33 @@ def test_parity_with_forced_paths(flags):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_two_training_steps_with_the_forward_xcd_map():
+    """GSR_FWD_XCD=1 (neighbouring tiles of the forward blend on one XCD) cannot host the spare workgroups that clear the backward's
+    accumulators; the forward must then clear them another way, or the SECOND step's gradients would carry the first step's sums
+    (ADVICE r3).  forward, backward, forward, backward in a fresh interpreter with the map on; both steps against the oracle."""
+    code = r'''
+import importlib, sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import conftest, parity
+from oracle import oracle
+gsr = importlib.import_module("3dgs-native_amd")
+bwd = importlib.import_module("3dgs-native_amd.backward").backward
+sc = gsr.scenes.synthetic_scene(5000, 0.05, 0.6, 33)
+cam = gsr.cameras.nerf_camera(gsr.scenes.LEGO_FRAME0, 176, 144, gsr.scenes.LEGO_CAMERA_ANGLE_X)
+kw = conftest.render_kwargs(sc, cam, width=176, height=144)
+ref = oracle.render_gaussians(**kw)
+skipped = []
+for step in range(3):
+    dpix = (np.random.default_rng(step).normal(0, 1, (144, 176, 3)) / (144 * 176 * 3)).astype(np.float32)
+    buf = gsr.render_gaussians(**kw)[2]
+    g = gsr.backward(**conftest.backward_kwargs(sc, cam, kw, buf, dpix))
+    skipped.append(bool(bwd.last_call_skipped_the_clear))
+    parity.compare_backward(g, oracle.backward(**conftest.backward_kwargs(sc, cam, kw, ref[2], dpix)))
+assert skipped == [False, True, True], skipped
+print("ok", skipped)
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, GSR_FWD_XCD="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

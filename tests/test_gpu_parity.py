@@ -402,6 +402,7 @@ def test_backward_accumulators_cleared_by_the_forward(oracle, cameras, scenes):
     gsr = pkg()
     from conftest import sub
     bwd = sub("backward").backward
+    sub("forward")._backward_seen = True     # (the pre-clear is lazy: it starts with the process's first backward(); see the test below)
     sc = scenes.synthetic_scene(6000, 0.05, 0.6, 77)
     cam = lego_camera(cameras, frame=6, width=192, height=160)
     kw = render_kwargs(sc, cam, width=192, height=160)
@@ -421,6 +422,92 @@ def test_backward_accumulators_cleared_by_the_forward(oracle, cameras, scenes):
     assert not bwd.last_call_skipped_the_clear
     parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix)), g_ref)     # the oracle's (numpy) buffers
     assert not bwd.last_call_skipped_the_clear
+
+
+def test_preclear_waits_for_the_first_backward(cameras, scenes):
+    """forward.PRECLEAR_BACKWARD is lazy: a process that has never called backward() (a render-only user) gets no backward workspace
+    allocated or cleared by its forwards; from the first backward() on, every forward pre-clears."""
+    gsr = pkg()
+    from conftest import sub
+    fwd, bwd, host = sub("forward"), sub("backward").backward, sub("_host")
+    sc = scenes.synthetic_scene(800, 0.05, 0.6, 12)
+    cam = lego_camera(cameras, 2, 96, 64)
+    kw = render_kwargs(sc, cam, width=96, height=64)
+    seen, fwd._backward_seen = fwd._backward_seen, False
+    try:
+        buf = gsr.render_gaussians(**kw)[2]
+        assert getattr(buf["point_list"], "_gsr_cleared_ws", None) is None
+        gsr.backward(**backward_kwargs(sc, cam, kw, buf, _pixel_grad(64, 96)))
+        assert not bwd.last_call_skipped_the_clear and fwd._backward_seen
+        buf = gsr.render_gaussians(**kw)[2]
+        assert getattr(buf["point_list"], "_gsr_cleared_ws", None) is not None
+        gsr.backward(**backward_kwargs(sc, cam, kw, buf, _pixel_grad(64, 96)))
+        assert bwd.last_call_skipped_the_clear
+    finally:
+        fwd._backward_seen = seen or fwd._backward_seen
+
+
+def test_in_place_writes_between_forward_and_backward_are_seen(oracle, cameras, scenes):
+    """The reference's backward() re-reads every array it is handed (backward.py:95-255 the SH rows and positions, :559-706 the
+    2-D means / conics / colours).  Ours reuses state the forward derived from them -- the d(colour)/d(direction) sums, the packed
+    blend records, the block masks -- and must drop it when the caller has written into the arrays IN PLACE since (same tensor
+    objects, new contents): torch's version counters are recorded in the tags.  Each case is compared with the oracle fed the
+    NEW arrays and the forward's (old) buffers, which is exactly what the reference would compute."""
+    import torch
+    gsr = pkg()
+    from conftest import sub
+    bwd = sub("backward").backward
+    sc = scenes.synthetic_scene(4000, 0.05, 0.6, 91)
+    cam = lego_camera(cameras, frame=3, width=176, height=144)
+    kw_np = render_kwargs(sc, cam, width=176, height=144)
+    ref = oracle.render_gaussians(**kw_np)
+    dpix = _pixel_grad(144, 176)
+
+    def fresh():
+        dev = {k: torch.as_tensor(np.ascontiguousarray(sc[k])).cuda() for k in ("means", "opacities", "scales", "rotations")}
+        dev["shs"] = torch.as_tensor(np.ascontiguousarray(sc["shs"])).cuda().reshape(-1, 3)
+        kw = dict(kw_np, means3D=dev["means"], opacity=dev["opacities"], scales=dev["scales"], rotations=dev["rotations"], sh=dev["shs"])
+        buf = gsr.render_gaussians(**kw)[2]
+        own = backward_kwargs(sc, cam, kw, buf, torch.as_tensor(dpix).cuda())
+        own.update(means3D=dev["means"], opacity=dev["opacities"], scales=dev["scales"], rotations=dev["rotations"], shs=dev["shs"])
+        return dev, buf, own
+
+    # untouched: every piece of forward state is reused
+    dev, buf, own = fresh()
+    parity.compare_backward(gsr.backward(**own), oracle.backward(**backward_kwargs(sc, cam, kw_np, ref[2], dpix)))
+    assert bwd.last_call_used_forward_sh_dir and bwd.last_call_used_forward_masks and bwd.last_call_used_forward_records
+
+    # SH coefficients scaled in place, positions nudged in place
+    dev, buf, own = fresh()
+    dev["shs"].mul_(1.1)
+    dev["means"].add_(torch.tensor([0.003, -0.002, 0.001], device="cuda"))
+    sc2 = dict(sc, shs=dev["shs"].cpu().numpy().reshape(sc["shs"].shape), means=dev["means"].cpu().numpy())
+    g = gsr.backward(**own)
+    assert not bwd.last_call_used_forward_sh_dir
+    assert bwd.last_call_used_forward_masks and bwd.last_call_used_forward_records      # these do not depend on shs / means3D
+    parity.compare_backward(g, oracle.backward(**backward_kwargs(sc2, cam, kw_np, ref[2], dpix)))
+
+    # the library's own in-place writer (Adam through raw pointers) counts as a write too
+    dev, buf, own = fresh()
+    P = {"positions": dev["means"], "scales": dev["scales"], "rotations": dev["rotations"], "opacities": dev["opacities"].reshape(-1), "shs": dev["shs"]}
+    G = {k: torch.full_like(v, 1e-3) for k, v in P.items()}
+    M, V = gsr.optimizer.make_state(P)
+    gsr.optimizer.adam_update(P, G, M, V, iteration=0)
+    sc3 = {"means": dev["means"].cpu().numpy(), "scales": dev["scales"].cpu().numpy(), "rotations": dev["rotations"].cpu().numpy(),
+           "opacities": dev["opacities"].cpu().numpy(), "shs": dev["shs"].cpu().numpy().reshape(sc["shs"].shape)}
+    g = gsr.backward(**own)
+    assert not bwd.last_call_used_forward_sh_dir
+    parity.compare_backward(g, oracle.backward(**backward_kwargs(sc3, cam, kw_np, ref[2], dpix)))
+
+    # a forward buffer written in place: conic_opacity (records and masks were derived from it), then the colours (records only)
+    for key, fwd_key in (("conic_opacity", "conic_opacity"), ("rgb", "colors")):
+        dev, buf, own = fresh()
+        buf[fwd_key].mul_(0.97)
+        ref_buf = dict(ref[2], **{fwd_key: buf[fwd_key].cpu().numpy()})
+        g = gsr.backward(**own)
+        assert not bwd.last_call_used_forward_records, key
+        assert bwd.last_call_used_forward_masks == (key == "rgb"), key
+        parity.compare_backward(g, oracle.backward(**backward_kwargs(sc, cam, kw_np, ref_buf, dpix)))
 
 
 def test_dL_dcov3D_is_a_dense_zero_array(cameras, scenes):
