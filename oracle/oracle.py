@@ -73,12 +73,29 @@ def _flat_opacity(op):
 TILE = 16
 
 
+def _bands(rows, threads):
+    """`rows` tile rows in at most `threads` contiguous bands."""
+    t = max(1, min(int(threads), rows))
+    cuts = [rows * k // t for k in range(t + 1)]
+    return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+def _in_threads(jobs):
+    """Run the ctypes calls (they release the GIL) of `jobs` concurrently, one thread each."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        for f in [ex.submit(j) for j in jobs]:
+            f.result()
+
+
 def render_gaussians(background, means3D, colors=None, opacity=None, scales=None, rotations=None,
                      scale_modifier=1.0, viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5,
                      image_height=256, image_width=256, sh=None, degree=3, campos=None,
                      prefiltered=False, antialiasing=False, clamped=True, debug=False,
-                     tile_rows=None, keep_keys=False):
-    """Restates forward.py:629-894.  `tile_rows=(y0,y1)` blends only those tile rows (bench sample)."""
+                     tile_rows=None, keep_keys=False, threads=1):
+    """Restates forward.py:629-894.  `tile_rows=(y0,y1)` blends only those tile rows (bench sample).  `threads` > 1 (bench.py's
+    all-cores courtesy figure) blends bands of tile rows concurrently: pixels are independent, so the
+    result is the same bit for bit, but it is not how the reference's CPU path runs (one serial loop)."""
     L = lib()
     H, W = int(image_height), int(image_width)
     means = _f32(means3D).reshape(-1, 3)
@@ -106,10 +123,15 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     tiles_touched = np.zeros(N, np.int32)
     clamped_state = np.zeros((N, 3), np.float32)
 
-    L.gsro_preprocess(C.c_int(N), _f(means), _f(sc), C.c_float(scale_modifier), _f(rot), _f(op), _f(shs),
-                      C.c_int(int(degree)), C.c_int(1 if clamped else 0), _f(view), _f(proj), _f(cam),
-                      C.c_int(W), C.c_int(H), C.c_float(tan_fovx), C.c_float(tan_fovy), _i(radii), _f(xy),
-                      _f(depths), _f(cov3Ds), _f(rgb), _f(conic_opacity), _i(tiles_touched), _f(clamped_state))
+    def pre(a, b):      # Gaussians [a, b): every array is per Gaussian, so a slice is a self-contained call
+        L.gsro_preprocess(C.c_int(b - a), _f(means[a:b]), _f(sc[a:b]), C.c_float(scale_modifier), _f(rot[a:b]), _f(op[a:b]), _f(shs[16 * a:16 * b]),
+                          C.c_int(int(degree)), C.c_int(1 if clamped else 0), _f(view), _f(proj), _f(cam),
+                          C.c_int(W), C.c_int(H), C.c_float(tan_fovx), C.c_float(tan_fovy), _i(radii[a:b]), _f(xy[a:b]),
+                          _f(depths[a:b]), _f(cov3Ds[a:b]), _f(rgb[a:b]), _f(conic_opacity[a:b]), _i(tiles_touched[a:b]), _f(clamped_state[a:b]))
+    if threads > 1 and N > 0:
+        _in_threads([(lambda a=a, b=b: pre(a, b)) for a, b in _bands(N, threads)])
+    else:
+        pre(0, N)
     point_offsets = np.zeros(N, np.int32)
     L.gsro_prefix_sum(C.c_int(N), _i(tiles_touched), _i(point_offsets))
     num_rendered = int(point_offsets[-1]) if N > 0 else 0            # forward.py:764 (N==0: Q10)
@@ -124,9 +146,13 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     if num_rendered > 0:
         L.gsro_identify_tile_ranges(C.c_int64(num_rendered), _l(keys), _i(ranges))
         y0, y1 = (0, gy) if tile_rows is None else tile_rows
-        L.gsro_render_rows(C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), _i(ranges), _i(point_list),
-                           _f(xy), _f(rgb), _f(conic_opacity), _f(depths), _f(bg), _f(image), _f(depth_image),
-                           _f(final_Ts), _i(n_contrib))
+        rows = lambda a, b: L.gsro_render_rows(C.c_int(W), C.c_int(H), C.c_int(a), C.c_int(b), _i(ranges), _i(point_list),
+                                               _f(xy), _f(rgb), _f(conic_opacity), _f(depths), _f(bg), _f(image), _f(depth_image),
+                                               _f(final_Ts), _i(n_contrib))
+        if threads > 1:
+            _in_threads([(lambda a=y0 + a, b=y0 + b: rows(a, b)) for a, b in _bands(y1 - y0, threads)])
+        else:
+            rows(y0, y1)
         # track_pixel_stats (forward.py:590-627) is unreachable after a real render (quirk Q9).
     out = {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths,
@@ -143,9 +169,11 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
              scale_modifier=1.0, viewmatrix=None, projmatrix=None, tan_fovx=0.5, tan_fovy=0.5,
              image_height=256, image_width=256, campos=None, radii=None, means2D=None,
              conic_opacity=None, rgb=None, clamped=None, cov3Ds=None, geom_buffer=None,
-             binning_buffer=None, img_buffer=None, degree=3, debug=False, tile_rows=None, accumulate="f32"):
+             binning_buffer=None, img_buffer=None, degree=3, debug=False, tile_rows=None, accumulate="f32", threads=1):
     """Restates backward.py:955-1196 (backward_render :890, backward_preprocess :770).  accumulate="f64" is NOT the
-    reference: it swaps the blend backward for the float64-accumulating second checker (gsro_render_backward_rows_acc64)."""
+    reference: it swaps the blend backward for the float64-accumulating second checker (gsro_render_backward_rows_acc64).
+    `threads` > 1 is NOT the reference either (bench.py's all-cores courtesy figure): bands of tile rows replay concurrently into
+    per-thread accumulators that are summed afterwards, so the float32 sums are formed in another order."""
     L = lib()
     H, W = int(image_height), int(image_width)
     focal_y = H / (2.0 * float(tan_fovy))                            # backward.py:1044-1045 (float64)
@@ -196,21 +224,36 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
                                           _f(bg), _f(m2d), _f(con), _f(col), _f(final_Ts), _i(n_contrib), _f(dpix),
                                           _d(acc[0]), _d(acc[1]), _d(acc[2]), _d(acc[3]))
         dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor = [np.ascontiguousarray(a, dtype=np.float32) for a in acc]
+    elif threads > 1:
+        bands = _bands(y1 - y0, threads)
+        priv = [(np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)) for _ in bands]
+        _in_threads([(lambda a=y0 + a, b=y0 + b, q=q: L.gsro_render_backward_rows(
+            C.c_int(W), C.c_int(H), C.c_int(a), C.c_int(b), _i(ranges), _i(point_list), _f(bg), _f(m2d), _f(con), _f(col), _f(final_Ts),
+            _i(n_contrib), _f(dpix), _f(q[0]), _f(q[1]), _f(q[2]), _f(q[3]))) for (a, b), q in zip(bands, priv)])
+        for q in priv:
+            dL_dmean2D += q[0]; dL_dconic += q[1]; dL_dopacity += q[2]; dL_dcolor += q[3]
     else:
         L.gsro_render_backward_rows(C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), _i(ranges), _i(point_list),
                                     _f(bg), _f(m2d), _f(con), _f(col), _f(final_Ts), _i(n_contrib), _f(dpix),
                                     _f(dL_dmean2D), _f(dL_dconic), _f(dL_dopacity), _f(dL_dcolor))
     dL_dcov3D = np.zeros((N, 6), np.float32)        # backward.py:812 (local)
-    L.gsro_cov2d_backward(C.c_int(N), _f(means), _f(c3), _i(radii), C.c_float(focal_x), C.c_float(focal_y),
-                          C.c_float(tan_fovx), C.c_float(tan_fovy), _f(view), _f(dL_dconic), _f(dL_dmean3D),
-                          _f(dL_dcov3D))
-    L.gsro_projection_backward(C.c_int(N), _f(means), _i(radii), _f(proj), _f(dL_dmean2D), _f(dL_dmean3D))
-    L.gsro_sh_backward(C.c_int(N), C.c_int(int(degree)), _f(means), _f(sh), _i(radii), _f(cam), _f(cl),
-                       _f(dL_dcolor), _f(dL_dmean3D), _f(dL_dsh))
-    # backward() never forwards scale_modifier to backward_preprocess (backward.py:1155-1182), whose
-    # default is 1.0 (:805): the cov3d backward always runs with scale_modifier = 1.0 (quirk Q16).
-    L.gsro_cov3d_backward(C.c_int(N), _f(sc), _f(rot), _i(radii), C.c_float(1.0), _f(dL_dcov3D),
-                          _f(dL_dscale), _f(dL_drot))
+
+    def geom(a, b):     # the four per-Gaussian kernels over Gaussians [a, b), in the reference's launch order
+        n = C.c_int(b - a)
+        L.gsro_cov2d_backward(n, _f(means[a:b]), _f(c3[a:b]), _i(radii[a:b]), C.c_float(focal_x), C.c_float(focal_y),
+                              C.c_float(tan_fovx), C.c_float(tan_fovy), _f(view), _f(dL_dconic[a:b]), _f(dL_dmean3D[a:b]),
+                              _f(dL_dcov3D[a:b]))
+        L.gsro_projection_backward(n, _f(means[a:b]), _i(radii[a:b]), _f(proj), _f(dL_dmean2D[a:b]), _f(dL_dmean3D[a:b]))
+        L.gsro_sh_backward(n, C.c_int(int(degree)), _f(means[a:b]), _f(sh[16 * a:16 * b]), _i(radii[a:b]), _f(cam), _f(cl[a:b]),
+                           _f(dL_dcolor[a:b]), _f(dL_dmean3D[a:b]), _f(dL_dsh[16 * a:16 * b]))
+        # backward() never forwards scale_modifier to backward_preprocess (backward.py:1155-1182), whose
+        # default is 1.0 (:805): the cov3d backward always runs with scale_modifier = 1.0 (quirk Q16).
+        L.gsro_cov3d_backward(n, _f(sc[a:b]), _f(rot[a:b]), _i(radii[a:b]), C.c_float(1.0), _f(dL_dcov3D[a:b]),
+                              _f(dL_dscale[a:b]), _f(dL_drot[a:b]))
+    if threads > 1 and N > 0:
+        _in_threads([(lambda a=a, b=b: geom(a, b)) for a, b in _bands(N, threads)])
+    else:
+        geom(0, N)
     return {
         "dL_dmean3D": dL_dmean3D, "dL_dcolor": dL_dcolor, "dL_dshs": dL_dsh, "dL_dopacity": dL_dopacity,
         "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,
