@@ -84,17 +84,6 @@ def tag_records(ws_tensor, n):
     return (ws_tensor, _ws_generation.get(id(ws_tensor), 0), n)
 
 
-def records_ptr(tag, n, dev):
-    """Device pointer of still-valid blend records, or NULL."""
-    if tag is None:
-        return C.c_void_p(0)
-    ws_tensor, gen, tn = tag
-    if (tn != n or ws_tensor.device != dev or _ws_generation.get(id(ws_tensor), 0) != gen
-            or _ws.get(("geom", dev.index, torch.cuda.current_stream(dev).cuda_stream)) is not ws_tensor):
-        return C.c_void_p(0)
-    return C.c_void_p(ws_tensor.data_ptr())
-
-
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
 

@@ -114,7 +114,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.gsr_abi_version() != 6:
+        if h.gsr_abi_version() != 7:
             raise RuntimeError("libgsr_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -71,15 +71,16 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
         conic_opacity = geom_buffer.get("conic_opacity") if conic_opacity is None else conic_opacity
         rgb = geom_buffer.get("rgb") if rgb is None else rgb
         clamped = geom_buffer.get("clamped_state") if clamped is None else clamped
-    rec_tag = getattr(means2D, "_gsr_records", None)     # set by render_gaussians on its points_xy_image tensor
+    # The forward's blend records (forward.py: means2D / conic_opacity / rgb are columns of one (N, 16) tensor) stand in for the
+    # three arrays when the caller hands back those very views, unwritten since: no re-pack, no packed copies of the views.
+    records = None
+    rec_tag = getattr(means2D, "_gsr_records", None)     # set by render_gaussians on its points_xy_image view
     if rec_tag is not None:
-        # the packed records are an image of means2D / conic_opacity / rgb as the forward wrote them: they stand in for the three
-        # arrays only if the caller hands back those very tensors, unwritten since (the reference re-reads the arrays)
-        src = rec_tag[3]
+        r_t, r_ver, src = rec_tag
         given3 = {"means2D": means2D, "conic_opacity": conic_opacity, "rgb": rgb}
-        fresh = all(src[k][0]() is given3[k] and _host.version_of(given3[k]) == src[k][1] for k in given3)
-        rec_tag = rec_tag[:3] if fresh else None
-    backward.last_call_used_forward_records = rec_tag is not None   # for tests and debugging (the workspace generation is checked below)
+        if all(src[k]() is given3[k] for k in given3) and r_t._version == r_ver and r_t.device == dev and r_t.shape[0] == N:
+            records = r_t
+    backward.last_call_used_forward_records = records is not None   # for tests and debugging
     # The forward's per-entry block masks ride on its point_list tensor.  They are conservative only for THAT forward's records
     # and written only up to each tile's saturation batch, so they are honoured only when every buffer they were derived from
     # or are read against is the forward's own tensor (identity, not equality): a caller who mixes in perturbed means2D /
@@ -105,9 +106,12 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
             sh_dir = d_t
     backward.last_call_used_forward_sh_dir = sh_dir is not None     # for tests and debugging
     radii = _host.to_dev(radii, i32, dev, (-1,))
-    m2d = _host.to_dev(means2D, f32, dev, (-1, 2))
-    con = _host.to_dev(conic_opacity, f32, dev, (-1, 4))
-    col = _host.to_dev(rgb, f32, dev, (-1, 3))
+    if records is None:      # (the reference re-reads the three arrays; so does this path -- packed copies if they are strided views)
+        m2d = _host.to_dev(means2D, f32, dev, (-1, 2))
+        con = _host.to_dev(conic_opacity, f32, dev, (-1, 4))
+        col = _host.to_dev(rgb, f32, dev, (-1, 3))
+    else:
+        m2d = con = col = None
     cl = _host.to_dev(clamped, f32, dev, (-1, 3))
     c3 = _host.to_dev(cov3Ds, f32, dev, (-1, 6))
     ranges = _host.to_dev(ranges, i32, dev, (-1, 2))
@@ -120,7 +124,7 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     scene = _lib.GsrScene(N, _host.ptr(means), _host.ptr(sc), _host.ptr(rot), _host.ptr(op), _host.ptr(sh), int(degree),
                           float(scale_modifier), 1)
     geom = _lib.GsrGeom(_host.ptr(radii), None, None, _host.ptr(m2d), None, _host.ptr(c3), _host.ptr(col), _host.ptr(con),
-                        _host.ptr(cl), _host.records_ptr(rec_tag, N, dev), _host.ptr(sh_dir))
+                        _host.ptr(cl), _host.ptr(records), _host.ptr(sh_dir))
     if masks is not None and not (isinstance(masks, torch.Tensor) and masks.dtype == torch.uint8 and masks.device == dev
                                   and masks.numel() == D and masks.is_contiguous()):
         masks = order = None

@@ -124,7 +124,9 @@ bool grads_aligned(const GsrGrads *g)
 
 bool geom_ok(const GsrGeom *g)
 {
-    return g && g->radii && g->tiles_touched && g->point_offsets && g->xy && g->depths && g->cov3D && g->rgb && g->conic_opacity &&
+    // xy / conic_opacity / rgb may be absent when the caller takes them as columns of its own record buffer (GsrGeom.blend_records)
+    const bool arrays = g && ((g->xy && g->rgb && g->conic_opacity) || g->blend_records);
+    return arrays && g->radii && g->tiles_touched && g->point_offsets && g->depths && g->cov3D &&
            g->clamped_state;
 }
 
@@ -502,7 +504,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
         clear = carve_bwd(binning->backward_ws, N).acc;
         clear_bytes = sizeof(GradRec) * (size_t)N;
     }
-    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, gw.rec, *image, binning->block_masks, file_order ? order : nullptr,
+    HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, geom->blend_records ? (const BlendRec *)geom->blend_records : gw.rec, *image, binning->block_masks, file_order ? order : nullptr,
                                      clear, clear_bytes, s));
     mark(st, 9, s);
     return GSR_OK;
@@ -513,7 +515,8 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
                                const GsrImage *image, const float *dL_dpixels, float *payload, void *ws, size_t ws_bytes, hipStream_t s, int st)
 {
     const int64_t N = scene->N;
-    if (!geom || !geom->radii || !geom->xy || !geom->cov3D || !geom->rgb || !geom->conic_opacity || !geom->clamped_state) return GSR_E_NULL;
+    if (!geom || !geom->radii || !geom->cov3D || !geom->clamped_state) return GSR_E_NULL;
+    if (!geom->blend_records && (!geom->xy || !geom->rgb || !geom->conic_opacity)) return GSR_E_NULL; // the records, or what they are rebuilt from
     if (!binning || !image || !dL_dpixels) return GSR_E_NULL;
     if (!geom_aligned(geom) || !gsr_aligned16(ws) || !gsr_aligned16(binning->point_list) || !gsr_aligned16(binning->ranges) ||
         !gsr_aligned16(binning->block_masks) || !gsr_aligned16(binning->block_order) ||

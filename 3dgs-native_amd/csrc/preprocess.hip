@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float *stage = reinterpret_cast<float *>(lds_wave);
     if (rows_valid > 0 && !GSR_ABL(dbg, 8)) {
         const float v_rgb[3] = {o_rgb[0], o_rgb[1], o_rgb[2]}, v_cl[3] = {o_cl[0], o_cl[1], o_cl[2]};
-        wave_store_rows<3>(rgb + 3 * wave_row0, stage, lane, rows_valid, v_rgb);
+        if (rgb) wave_store_rows<3>(rgb + 3 * wave_row0, stage, lane, rows_valid, v_rgb); // (absent: the caller reads the record's columns)
         wave_store_rows<3>(clamped_state + 3 * wave_row0, stage + 256, lane, rows_valid, v_cl);
         wave_store_rows<6>(cov3Ds + 6 * wave_row0, stage + 512, lane, rows_valid, o_cov);
         const float inv_depth = visible ? 1.0f / o_depth : 0.0f;
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     if (GSR_ABL(dbg, 8)) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
     radii[i] = o_radius;
     tiles_touched[i] = o_tiles;
-    *reinterpret_cast<float2 *>(xy + 2 * i) = make_float2(o_xy[0], o_xy[1]);
+    if (xy) *reinterpret_cast<float2 *>(xy + 2 * i) = make_float2(o_xy[0], o_xy[1]);
     depths[i] = o_depth;
-    *reinterpret_cast<float4 *>(conic_opacity + 4 * i) = make_float4(o_con[0], o_con[1], o_con[2], o_con[3]);
+    if (conic_opacity) *reinterpret_cast<float4 *>(conic_opacity + 4 * i) = make_float4(o_con[0], o_con[1], o_con[2], o_con[3]);
     }
 
     // internal products
@@ -307,7 +307,8 @@ hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrG
     const unsigned blocks = (unsigned)gsr_div_up(sc.N, threads);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
-                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state, ws.rec, ws.rect, ws.depth_item, ws.acc[0],
+                       g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state,
+                       g.blend_records ? (BlendRec *)g.blend_records : ws.rec /* the caller's record buffer, else the workspace's */, ws.rect, ws.depth_item, ws.acc[0],
                        3 * (int)gsr_radix_acc_ints(sc.N) /* acc[0], acc[1] (the depth sort may start at a later pass) and acc_first */, ws.scan_tmp, g.sh_dir_grad,
                        ws.blk_minmax, gsr_debug_flags);
     return hipGetLastError();

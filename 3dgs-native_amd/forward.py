@@ -19,7 +19,8 @@ from .config import TILE_M, TILE_N
 # process never pays for it); the first training step's backward clears for itself.
 PRECLEAR_BACKWARD = not bool(int(os.environ.get("GSR_NO_PRECLEAR", "0")))
 _backward_seen = False          # set by backward.backward()
-_NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))   # A/B switch: backward reads the SH rows itself (same results)
+_NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))
+_NO_RECORD_VIEWS = bool(int(os.environ.get("GSR_NO_RECORD_VIEWS", "0")))   # A/B switch: packed xy / conic_opacity / colors arrays beside the records   # A/B switch: backward reads the SH rows itself (same results)
 
 
 def render_gaussians(background, means3D, colors=None, opacity=None, scales=None, rotations=None, scale_modifier=1.0,
@@ -48,15 +49,22 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
                           int(degree), float(scale_modifier), 1 if clamped else 0)
     e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
     radii, tiles_touched, point_offsets = e((N,), i32), e((N,), i32), e((N,), i32)
-    xy, depths, cov3Ds, rgb = e((N, 2), f32), e((N,), f32), e((N, 6), f32), e((N, 3), f32)
-    conic_opacity, clamped_state = e((N, 4), f32), e((N, 3), f32)
+    # points_xy_image, conic_opacity and colors are COLUMNS of this call's blend records (one 64-byte row per Gaussian: x, y, conic
+    # a b c, opacity, r g b, 1/depth -- GsrGeom.blend_records): strided views, so the forward writes those 36 bytes per Gaussian once
+    # instead of twice.  `.cpu().numpy()`, indexing and arithmetic work on them as on any tensor; `.contiguous()` gives a packed copy.
+    records = e((N, 16), f32)
+    xy, conic_opacity, rgb = records[:, 0:2], records[:, 2:6], records[:, 6:9]
+    if _NO_RECORD_VIEWS:
+        xy, conic_opacity, rgb = e((N, 2), f32), e((N, 4), f32), e((N, 3), f32)
+    depths, cov3Ds, clamped_state = e((N,), f32), e((N, 6), f32), e((N, 3), f32)
     # d(colour)/d(direction), nine floats per Gaussian: what the SH backward needs of the 48 coefficients (GsrGeom.sh_dir_grad).
     # Only worth its 36 bytes per Gaussian when the caller's SH / position tensors can be recognised again by backward(), i.e.
     # when they are device tensors used in place.
     in_place = lambda given, used: isinstance(given, torch.Tensor) and given.is_cuda and given.data_ptr() == used.data_ptr()
     sh_dir = e((N, 9), f32) if (N > 0 and in_place(sh, shs) and in_place(means3D, means) and not _NO_SH_DIR) else None
-    geom = _lib.GsrGeom(_host.ptr(radii), _host.ptr(tiles_touched), _host.ptr(point_offsets), _host.ptr(xy), _host.ptr(depths),
-                        _host.ptr(cov3Ds), _host.ptr(rgb), _host.ptr(conic_opacity), _host.ptr(clamped_state), None, _host.ptr(sh_dir))
+    arr = (lambda t: _host.ptr(t)) if _NO_RECORD_VIEWS else (lambda t: None)
+    geom = _lib.GsrGeom(_host.ptr(radii), _host.ptr(tiles_touched), _host.ptr(point_offsets), arr(xy), _host.ptr(depths),
+                        _host.ptr(cov3Ds), arr(rgb), arr(conic_opacity), _host.ptr(clamped_state), _host.ptr(records), _host.ptr(sh_dir))
     image, depth_image = e((H, W, 3), f32), e((H, W), f32)
     final_Ts, n_contrib = e((H, W), f32), e((H, W), i32)
     img = _lib.GsrImage(_host.ptr(image), _host.ptr(depth_image), _host.ptr(final_Ts), _host.ptr(n_contrib))
@@ -87,13 +95,11 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
         _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
                                         _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
-    # Let a following backward() reuse the packed blend records this call left in the geom workspace:
-    # the tag rides on the means2D tensor (the reference's callers re-pack the dicts by hand, train.py:986-1000)
-    # and is honoured only while no later forward has overwritten that workspace.
+    # Let a following backward() use the records as they are: the tag rides on the means2D view (the reference's callers re-pack
+    # the dicts by hand, train.py:986-1000) and is honoured when backward() is handed these very three views, unwritten since
+    # (views share their base's version counter, so a write through any of them, or into the records, is seen).
     if N > 0:
-        # (the records are an image of these three arrays as this call wrote them: identity AND version are checked)
-        xy._gsr_records = _host.tag_records(gws, N) + ({"means2D": (weakref.ref(xy), xy._version), "conic_opacity": (weakref.ref(conic_opacity), conic_opacity._version),
-                                                        "rgb": (weakref.ref(rgb), rgb._version)},)
+        xy._gsr_records = (records, records._version, {"means2D": weakref.ref(xy), "conic_opacity": weakref.ref(conic_opacity), "rgb": weakref.ref(rgb)})
         # likewise the block masks ride on the point_list tensor (their own allocation, alive as long as it is): a caller
         # that hands backward() this very tensor gets the mask-driven compaction, anyone else the self-contained one
         # -- and only together with the other buffers of this call (backward() checks identity): the masks describe these

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 #define GSR_TILE 16
 #define GSR_SH_STRIDE 16 /* SH coefficients per Gaussian, always 16 (reference forward.py:310) */
 #define GSR_MAX_RENDERED (1LL << 30) /* reference forward.py:765-767 */
@@ -97,9 +97,17 @@ typedef struct GsrGeom {
     float *rgb;             /* [N*3] */
     float *conic_opacity;   /* [N*4] */
     float *clamped_state;   /* [N*3] */
-    const void *blend_records; /* optional, gsr_backward only: the N 64-byte blend records gsr_forward_count
-                                  left at the START of geom_ws, if the caller still holds that buffer
-                                  unmodified; NULL -> rebuilt from xy / conic_opacity / rgb (same values) */
+    void *blend_records;    /* optional [N*16 floats = N 64-byte records, 64-byte rows]: per Gaussian (x, y, conic a, b, c, opacity,
+                               r, g, b, 1/depth, 0 ...) -- xy, conic_opacity and rgb of the same Gaussian in one row, the unit the
+                               blend kernels gather.
+                               gsr_forward_count / gsr_forward_render (ABI 7): given a buffer, the forward keeps its records THERE
+                               instead of in geom_ws, and `xy`, `conic_opacity`, `rgb` may then each be NULL: their values are
+                               columns 0-1, 2-5 and 6-8 of the records (a caller exposes them as strided views), and the forward
+                               saves writing them twice (36 of its 200 bytes per Gaussian).  Arrays that are given are still written.
+                               gsr_backward / gsr_backward_blend: the records of the forward call (this buffer, or -- for a
+                               forward that was given none -- the START of its geom_ws, if still unmodified); `xy`,
+                               `conic_opacity`, `rgb` are then not read and may be NULL.  NULL -> rebuilt from xy / conic_opacity
+                               / rgb (same values). */
     float *sh_dir_grad;     /* optional [N*9], not part of the reference's dict.  gsr_forward_count, given a buffer, writes per
                                visible Gaussian the nine sums d(colour before clamping)/d(view direction) that the SH backward
                                (backward.py:120-244) forms from the 48 coefficients: (d/dx, d/dy, d/dz) x (r, g, b), the same

@@ -15,6 +15,8 @@
  * holds for the rasterizer entry points only:
  *   real:  gsr_abi_version, gsr_strerror, gsr_build_flags, gsr_*_workspace_bytes, gsr_forward_count, gsr_forward_render,
  *          gsr_backward, gsr_l1_loss_grad, gsr_ssim, gsr_depth_loss, gsr_adam_update
+ *   (records-only mode -- GsrGeom.blend_records as the forward's output with xy / conic_opacity / rgb NULL, ABI 7 -- is not
+ *   offered here: the three arrays are required, GSR_E_NULL otherwise; a given blend_records buffer is ignored by the forward)
  *   stubs (return GSR_E_HIP, or a constant for the sizing / timing helpers):  gsr_backward_blend, gsr_backward_geom,
  *          gsr_sh_grad_from_views, gsr_adam_update_views, gsr_densify_mark, gsr_prune_mark, gsr_split_removal_mask, gsr_mask_scan,
  *          gsr_mask_scan_workspace_bytes, gsr_block_order_ints, gsr_clone_gaussians, gsr_split_gaussians, gsr_compact_gaussians,

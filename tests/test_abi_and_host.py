@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(libpath):
 def test_host_only_entry_points(libpath):
     _lib = sub("_lib")
     L = _lib.lib()
-    assert L.gsr_abi_version() == 6
+    assert L.gsr_abi_version() == 7
     assert _lib.strerror(0) == "ok" and "2^30" in _lib.strerror(_lib.GSR_E_OVERFLOW)
     a, b = L.gsr_geom_workspace_bytes(1000), L.gsr_geom_workspace_bytes(2000)
     assert 0 < a < b and b >= 2000 * (64 + 8 + 8)
@@ -148,7 +148,7 @@ def test_header_is_plain_c_and_client_links(tmp_path):
     tests/c_abi must link against the library with nothing but the HIP runtime."""
     import subprocess
     probe = tmp_path / "probe.c"
-    probe.write_text('#include "gsr.h"\nint main(void) { GsrScene s; GsrParams p; (void)s; (void)p; return GSR_ABI_VERSION == 6 ? 0 : 1; }\n')
+    probe.write_text('#include "gsr.h"\nint main(void) { GsrScene s; GsrParams p; (void)s; (void)p; return GSR_ABI_VERSION == 7 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)])
     subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "tests", "c_abi")])
     assert os.path.exists(os.path.join(ROOT, "tests", "c_abi", "gsr_client"))

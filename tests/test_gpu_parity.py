@@ -499,15 +499,56 @@ def test_in_place_writes_between_forward_and_backward_are_seen(oracle, cameras, 
     assert not bwd.last_call_used_forward_sh_dir
     parity.compare_backward(g, oracle.backward(**backward_kwargs(sc3, cam, kw_np, ref[2], dpix)))
 
-    # a forward buffer written in place: conic_opacity (records and masks were derived from it), then the colours (records only)
+    # a forward buffer written in place: conic_opacity (records and masks were derived from it), then the colours (records only --
+    # but the colours are a view of the same records tensor as means2D / conic_opacity and share its version counter, so the masks
+    # are dropped with them: conservative, the self-contained block test gives the same gradients)
     for key, fwd_key in (("conic_opacity", "conic_opacity"), ("rgb", "colors")):
         dev, buf, own = fresh()
         buf[fwd_key].mul_(0.97)
         ref_buf = dict(ref[2], **{fwd_key: buf[fwd_key].cpu().numpy()})
         g = gsr.backward(**own)
         assert not bwd.last_call_used_forward_records, key
-        assert bwd.last_call_used_forward_masks == (key == "rgb"), key
+        assert not bwd.last_call_used_forward_masks, key
         parity.compare_backward(g, oracle.backward(**backward_kwargs(sc, cam, kw_np, ref_buf, dpix)))
+
+
+def test_xy_conic_and_colours_are_columns_of_the_blend_records(oracle, cameras, scenes):
+    """ABI 7: the forward writes points_xy_image / conic_opacity / colors ONCE, as columns 0-1 / 2-5 / 6-8 of its 64-byte blend
+    records (GsrGeom.blend_records with xy = conic_opacity = rgb = NULL); the dict entries are strided views of that one tensor.
+    They must still behave like the reference's arrays for a caller (values, shapes, numpy conversion, arithmetic, packed copies),
+    backward() must take the records as they are when handed the views back, and re-read packed copies (or anything else) when not."""
+    import torch
+    gsr = pkg()
+    from conftest import sub
+    bwd = sub("backward").backward
+    sc = scenes.synthetic_scene(3000, 0.05, 0.6, 19)
+    cam = lego_camera(cameras, frame=5, width=160, height=128)
+    kw = render_kwargs(sc, cam, width=160, height=128)
+    ref = oracle.render_gaussians(**kw)
+    img, _, buf = gsr.render_gaussians(**kw)
+    parity.compare_forward((img, _, buf), ref)
+    xy, con, col = buf["points_xy_image"], buf["conic_opacity"], buf["colors"]
+    assert tuple(xy.shape) == (3000, 2) and tuple(con.shape) == (3000, 4) and tuple(col.shape) == (3000, 3)
+    base = xy._base
+    assert base is not None and con._base is base and col._base is base and tuple(base.shape) == (3000, 16) and base.is_contiguous()
+    assert xy.stride() == (16, 1) and con.data_ptr() == base.data_ptr() + 8 and col.data_ptr() == base.data_ptr() + 24
+    vis = ref[2]["radii"] > 0
+    np.testing.assert_array_equal(base[:, 9].cpu().numpy()[vis], (np.float32(1.0) / ref[2]["depths"][vis]).astype(np.float32))   # 1 / depth rides along
+    assert float(base[:, 10:].abs().max()) == 0.0
+    for t, k in ((xy, "points_xy_image"), (con, "conic_opacity"), (col, "colors")):
+        a = t.cpu().numpy()
+        assert a.flags["C_CONTIGUOUS"] and t.contiguous().is_contiguous() and (t * 2.0).shape == t.shape
+        np.testing.assert_array_equal(np.asarray(t.cpu()), a)
+    dpix = _pixel_grad(128, 160)
+    g_ref = oracle.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix))
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf, dpix)), g_ref)
+    assert bwd.last_call_used_forward_records
+    packed = dict(buf, points_xy_image=xy.contiguous(), conic_opacity=con.contiguous(), colors=col.contiguous())
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, packed, dpix)), g_ref)       # packed copies: re-packed by the backward
+    assert not bwd.last_call_used_forward_records
+    host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in buf.items()}
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, host, dpix)), g_ref)         # numpy arrays, as the reference's callers hold
+    assert not bwd.last_call_used_forward_records
 
 
 def test_dL_dcov3D_is_a_dense_zero_array(cameras, scenes):
