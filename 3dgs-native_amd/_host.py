@@ -68,22 +68,6 @@ def workspace(kind, nbytes, dev):
     return t
 
 
-_ws_generation = {}
-
-
-def workspace_written(t):
-    """Record that a forward call is about to overwrite workspace tensor `t`."""
-    _ws_generation[id(t)] = _ws_generation.get(id(t), 0) + 1
-
-
-def generation_of(t):
-    return _ws_generation.get(id(t), 0)
-
-
-def tag_records(ws_tensor, n):
-    return (ws_tensor, _ws_generation.get(id(ws_tensor), 0), n)
-
-
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
 

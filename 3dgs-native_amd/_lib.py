@@ -66,6 +66,7 @@ EXPORTS = {
     "gsr_geom_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gsr_binning_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "gsr_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "gsr_backward_accumulators_offset": (C.c_size_t, [C.c_int64]),
     "gsr_block_order_ints": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gsr_forward_count": (C.c_int, [C.POINTER(GsrScene), C.POINTER(GsrCamera), C.POINTER(GsrGeom), vp, C.c_size_t,
                                     C.POINTER(C.c_int64), vp]),

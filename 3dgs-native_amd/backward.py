@@ -21,6 +21,8 @@ from . import _host, _lib
 
 
 _ZERO = {}
+import os
+_NO_GRAD_VIEWS = bool(int(os.environ.get("GSR_NO_GRAD_VIEWS", "0")))   # A/B switch: packed dL_dcolor / dL_dmean2D / dL_dconic arrays
 
 
 def _zeros_cov3d(n, dev):
@@ -149,17 +151,28 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     dL_dscale = arena[o[1]:o[1] + 3 * N].view(N, 3)
     dL_drot = arena[o[2]:o[2] + 4 * N].view(N, 4)
     dL_dopacity = arena[o[3]:o[3] + N]
-    dL_dcolor = torch.empty((N, 3), dtype=f32, device=dev)
-    dL_dmean2D = torch.empty((N, 3), dtype=f32, device=dev)
-    dL_dconic = torch.empty((N, 4), dtype=f32, device=dev)
-    grads = _lib.GsrGrads(_host.ptr(dL_dmean3D), _host.ptr(dL_dscale), _host.ptr(dL_drot), _host.ptr(dL_dopacity),
-                          _host.ptr(dL_dsh), _host.ptr(dL_dcolor), _host.ptr(dL_dmean2D), _host.ptr(dL_dconic), _host.ptr(payload))
     with torch.cuda.device(dev):
-        ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
-        # the forward cleared this workspace's accumulators in its blend kernel, and no backward has used it since?
-        cleared = (cleared_tag is not None and cleared_tag[0] is ws and cleared_tag[2] == N
-                   and _host.generation_of(ws) == cleared_tag[1])
-        _host.workspace_written(ws)                     # ... it is used now
+        # The workspace belongs to THIS call (the returned blend-stage gradients are views of it).  If the forward made one and
+        # cleared its accumulators in its blend kernel -- and no backward has taken it yet -- it is that one; else a fresh one,
+        # which the library clears itself.
+        need = int(L.gsr_backward_workspace_bytes(N, D, W, H))
+        cleared = (cleared_tag is not None and cleared_tag[0] is not None and cleared_tag[1] == N and cleared_tag[0].device == dev
+                   and cleared_tag[0].numel() >= need)
+        if cleared:
+            ws, cleared_tag[0] = cleared_tag[0], None   # taken: a second backward() on the same forward gets a fresh one
+        else:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        # dL_dcolor / dL_dmean2D / dL_dconic are columns 0-2 / 3-5 / 6-9 of the accumulator records the blend backward sums into
+        # (gsr.h GsrGrads): strided views, so the per-Gaussian kernel does not write 40 bytes per Gaussian of copies
+        off = int(L.gsr_backward_accumulators_offset(N))
+        acc = ws[off:off + 64 * N].view(f32).view(N, 16)
+        dL_dcolor, dL_dmean2D, dL_dconic = acc[:, 0:3], acc[:, 3:6], acc[:, 6:10]
+        packed = (lambda t: None)
+        if _NO_GRAD_VIEWS:
+            dL_dcolor, dL_dmean2D, dL_dconic = (torch.empty((N, k), dtype=f32, device=dev) for k in (3, 3, 4))
+            packed = _host.ptr
+        grads = _lib.GsrGrads(_host.ptr(dL_dmean3D), _host.ptr(dL_dscale), _host.ptr(dL_drot), _host.ptr(dL_dopacity),
+                              _host.ptr(dL_dsh), packed(dL_dcolor), packed(dL_dmean2D), packed(dL_dconic), _host.ptr(payload))
         binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(masks), _host.ptr(order),
                                   _host.ptr(ws) if cleared else None, 1 if cleared else 0)
         backward.last_call_skipped_the_clear = cleared     # for tests and debugging

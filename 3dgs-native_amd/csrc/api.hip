@@ -337,6 +337,7 @@ const char *gsr_strerror(int code)
 size_t gsr_geom_workspace_bytes(int64_t N) { return gsr_carve_geom(nullptr, N < 0 ? 0 : N).bytes; }
 size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t, int32_t) { return carve_bin(nullptr, N < 0 ? 0 : N, D < 0 ? 0 : D).bytes; }
 size_t gsr_backward_workspace_bytes(int64_t N, int64_t, int32_t, int32_t) { return carve_bwd(nullptr, N < 0 ? 0 : N).bytes; }
+size_t gsr_backward_accumulators_offset(int64_t N) { return gsr_align((size_t)(N < 0 ? 0 : N) * sizeof(BlendRec)); } // carve_bwd: the records come first
 size_t gsr_block_order_ints(int32_t W, int32_t H)
 {
     if (W <= 0 || H <= 0) return 0;
@@ -550,9 +551,8 @@ static int backward_geom_impl(const GsrScene *scene, const GsrCamera *camera, co
 {
     const int64_t N = scene->N;
     // dL_dshs and dL_drgb may both be NULL here: the payload was taken from the blend half and the SH gradient is rebuilt later
-    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || !grads->dL_dcolor ||
-        !grads->dL_dmean2D || !grads->dL_dconic)
-        return GSR_E_NULL;
+    // (dL_dcolor / dL_dmean2D / dL_dconic may each be NULL: they are columns of the accumulator records in `ws`, gsr.h GsrGrads)
+    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity) return GSR_E_NULL;
     if (!geom || !geom->radii || !geom->cov3D || !geom->clamped_state) return GSR_E_NULL;
     if (!geom_aligned(geom) || !grads_aligned(grads) || !gsr_aligned16(ws)) return GSR_E_ALIGN;
     if (!ws || ws_bytes < gsr_backward_workspace_bytes(N, 0, camera->W, camera->H)) return GSR_E_WORKSPACE;
@@ -569,8 +569,7 @@ int gsr_backward(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *
     read_tuning();
     if (int rc = check_scene_cam(scene, camera)) return rc;
     if (scene->N == 0) return GSR_OK;
-    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || (!grads->dL_dshs && !grads->dL_drgb) ||
-        !grads->dL_dcolor || !grads->dL_dmean2D || !grads->dL_dconic)
+    if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity || (!grads->dL_dshs && !grads->dL_drgb))
         return GSR_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     const int st = timer_open(false);

@@ -463,12 +463,12 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         s_g[lane][0] = g_c0; s_g[lane][1] = g_c1; s_g[lane][2] = g_c2; s_g[lane][3] = g_mx; s_g[lane][4] = g_my;
         s_g[lane][5] = g_ca; s_g[lane][6] = g_cb; s_g[lane][7] = g_cc; s_g[lane][8] = g_op;
         __syncthreads();
-        const int c = lane & 15;
+        const int c = lane & 15, fslot = gsr_gradrec_slot(c); // the record's layout leaves the API arrays' zero columns free
 #pragma unroll 4
         for (int r = 0; r < 16; ++r) {
             const int e = r * 4 + (lane >> 4);
             const int eid = s_id[e];
-            if (c < 9 && eid >= 0 && !GSR_ABL(dbg, 1)) unsafeAtomicAdd(&acc[eid].f[c], s_g[e][c]);
+            if (c < 9 && eid >= 0 && !GSR_ABL(dbg, 1)) unsafeAtomicAdd(&acc[eid].f[fslot], s_g[e][c]);
         }
         __syncthreads();
         TL(4) // flush

@@ -111,14 +111,14 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     if (in_range) {
 
     const float4 *ap = reinterpret_cast<const float4 *>(acc + idx);
-    const float4 a0 = ap[0], a1 = ap[1];
-    const float a8 = acc[idx].f[8];
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2]; // GradRec: r g b | x y 0 | a b 0 c | opacity
+    const float a8 = a2.z;
     g_col[0] = a0.x; g_col[1] = a0.y; g_col[2] = a0.z;
     g_m2d[0] = a0.w; g_m2d[1] = a1.x;
-    g_con[0] = a1.y; g_con[1] = a1.z; g_con[2] = a1.w; // d/da, d/db, d/dc
-    // API-layout copies of the blend-stage gradients
+    g_con[0] = a1.z; g_con[1] = a1.w; g_con[2] = a2.y; // d/da, d/db, d/dc
+    // API-layout copies of the blend-stage gradients, for a caller that wants packed arrays (NULL: it reads the record's columns)
     // (dL_dcolor and dL_dmean2D: 12-byte rows, written wave-cooperatively at the end of the kernel)
-    *reinterpret_cast<float4 *>(dL_dconic + 4 * idx) = make_float4(g_con[0], g_con[1], 0.0f, g_con[2]);
+    if (dL_dconic) *reinterpret_cast<float4 *>(dL_dconic + 4 * idx) = make_float4(g_con[0], g_con[1], 0.0f, g_con[2]);
     dL_dopacity[idx] = a8;
 
     vis = my_radius > 0;
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     // the 12-byte-row outputs leave through the pad float4 of the wave's LDS rows as whole float4 lines (sh_stage.h): as
     // per-lane scalar stores each of these arrays cost three instructions over 64 partial lines
     if (rows_valid > 0) {
-        wave_store_vec3_in_pad(dL_dcolor + 3 * wave_row0, lds_wave, lane, rows_valid, g_col[0], g_col[1], g_col[2]);
-        wave_store_vec3_in_pad(dL_dmean2D + 3 * wave_row0, lds_wave, lane, rows_valid, g_m2d[0], g_m2d[1], 0.0f);
+        if (dL_dcolor) wave_store_vec3_in_pad(dL_dcolor + 3 * wave_row0, lds_wave, lane, rows_valid, g_col[0], g_col[1], g_col[2]);
+        if (dL_dmean2D) wave_store_vec3_in_pad(dL_dmean2D + 3 * wave_row0, lds_wave, lane, rows_valid, g_m2d[0], g_m2d[1], 0.0f);
         wave_store_vec3_in_pad(dL_dmean3D + 3 * wave_row0, lds_wave, lane, rows_valid, o_mean[0], o_mean[1], o_mean[2]);
         wave_store_vec3_in_pad(dL_dscale + 3 * wave_row0, lds_wave, lane, rows_valid, o_scale[0], o_scale[1], o_scale[2]);
         if (dL_drgb) wave_store_vec3_in_pad(dL_drgb + 3 * wave_row0, lds_wave, lane, rows_valid, o_rgb[0], o_rgb[1], o_rgb[2]);

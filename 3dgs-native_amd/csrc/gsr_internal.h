@@ -176,8 +176,13 @@ hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, cons
 
 // backward
 struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (atomics target)
-    float f[16];                              // 0..2 dcolor, 3..4 dmean2D, 5..7 dconic(a,b,c), 8 dopacity
+    float f[16];                              // 0..2 dcolor | 3..4 dmean2D, 5 = 0 | 6..7 dconic a b, 8 = 0, 9 dconic c | 10 dopacity | 0 ...
 };
+// The nine accumulated values sit where the reference's API arrays have them: columns 0-2, 3-5 and 6-9 of the record ARE
+// dL_dcolor (N,3), dL_dmean2D (N,3: z = 0) and dL_dconic (N,4: a, b, 0, c), so a caller that owns the backward workspace per call
+// reads them as strided views (include/gsr.h, GsrGrads) and geom_backward_kernel need not write 40 bytes per Gaussian of copies.
+// k-th accumulated value (colour r g b, mean2D x y, conic a b c, opacity) -> float index in the record
+__host__ __device__ static inline int gsr_gradrec_slot(int k) { return k + (k >= 5) + (k >= 7); }
 hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, hipStream_t s);
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                            const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,

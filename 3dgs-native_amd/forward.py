@@ -73,7 +73,6 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
 
     with torch.cuda.device(dev):
         gws = _host.workspace("geom", L.gsr_geom_workspace_bytes(N), dev)
-        _host.workspace_written(gws)
         D = C.c_int64(0)
         _lib.check(L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), _host.ptr(gws), gws.numel(),
                                        C.byref(D), stream))
@@ -86,10 +85,12 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         block_masks = e((D + 16,), torch.uint8)[:D]
         # the backward blend's blocks filed by cost, heaviest first (GsrBinning.block_order): filled by the forward blend from the masks
         block_order = e((int(L.gsr_block_order_ints(W, H)),), i32)
+        # The backward's workspace, one per call: its accumulator records are what backward() returns dL_dcolor / dL_dmean2D /
+        # dL_dconic as views of, so it must not be shared between calls.  Handed to the forward, its records are cleared by the
+        # blend kernel's spare workgroups.
         bwd_ws = None
         if PRECLEAR_BACKWARD and _backward_seen and N > 0 and D > 0:
-            bwd_ws = _host.workspace("bwd", L.gsr_backward_workspace_bytes(N, D, W, H), dev)
-            _host.workspace_written(bwd_ws)
+            bwd_ws = e((int(L.gsr_backward_workspace_bytes(N, D, W, H)),), torch.uint8)
         binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks), _host.ptr(block_order),
                                   _host.ptr(bwd_ws), 0)
         bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
@@ -113,8 +114,8 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
                                          sh._version, means3D._version)
         owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
         point_list._gsr_block_masks = (block_masks, {k: (weakref.ref(v), v._version) for k, v in owners.items()}, block_order)
-        if bwd_ws is not None:      # "this backward workspace has clean accumulators as of this generation" (backward() checks)
-            point_list._gsr_cleared_ws = _host.tag_records(bwd_ws, N)
+        if bwd_ws is not None:      # "a backward workspace with clean accumulators": the first backward() handed this point_list takes it
+            point_list._gsr_cleared_ws = [bwd_ws, N]
     return image, depth_image, {
         "radii": radii, "point_offsets": point_offsets, "points_xy_image": xy, "depths": depths, "colors": rgb,
         "cov3Ds": cov3Ds, "conic_opacity": conic_opacity, "point_list": point_list, "ranges": ranges,

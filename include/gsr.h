@@ -162,9 +162,14 @@ typedef struct GsrGrads {
     float *dL_drot;     /* [N*4] (x,y,z,w) */
     float *dL_dopacity; /* [N] */
     float *dL_dshs;     /* [N*16*3] */
-    float *dL_dcolor;   /* [N*3] */
-    float *dL_dmean2D;  /* [N*3] (z = 0) */
-    float *dL_dconic;   /* [N*4] (a, b, 0, c) */
+    /* The three blend-stage gradients below may each be NULL (ABI 7).  They are plain copies of what the blend backward accumulates
+     * per Gaussian in its 64-byte accumulator records, which start gsr_backward_accumulators_offset(N) bytes into `ws` as N rows of
+     * 16 floats laid out like the API arrays: columns 0-2 = dL_dcolor, 3-5 = dL_dmean2D (z = 0), 6-9 = dL_dconic (a, b, 0, c),
+     * 10 = dL_dopacity, the rest zero.  A caller that gives every gsr_backward call a `ws` of its own exposes those columns as
+     * strided views (3dgs-native_amd/backward.py does) and the per-Gaussian kernel writes 40 bytes per Gaussian less. */
+    float *dL_dcolor;   /* [N*3] or NULL */
+    float *dL_dmean2D;  /* [N*3] (z = 0) or NULL */
+    float *dL_dconic;   /* [N*4] (a, b, 0, c) or NULL */
     /* Optional (view-parallel training, see gsr_sh_grad_from_views): this view's PAYLOAD, [N*3 + 4] floats =
      * N rows of the colour gradient the SH backward starts from, dL_dcolor * (1 - clamped) (backward.py:88-92; zero for
      * Gaussians that get no SH gradient), then the camera position (3 floats) and a zero.  When it is given, dL_dshs may
@@ -183,6 +188,7 @@ int gsr_build_flags(void);
 size_t gsr_geom_workspace_bytes(int64_t N);
 size_t gsr_binning_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
 size_t gsr_backward_workspace_bytes(int64_t N, int64_t D, int32_t W, int32_t H);
+size_t gsr_backward_accumulators_offset(int64_t N); /* byte offset of the accumulator records inside that workspace (GsrGrads) */
 size_t gsr_block_order_ints(int32_t W, int32_t H); /* int32 elements of GsrBinning.block_order for a W x H image */
 
 /* Stage 1 of render_gaussians: wp_preprocess + wp_prefix_sum + the D readback

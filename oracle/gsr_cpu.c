@@ -19,7 +19,7 @@
  *   offered here: the three arrays are required, GSR_E_NULL otherwise; a given blend_records buffer is ignored by the forward)
  *   stubs (return GSR_E_HIP, or a constant for the sizing / timing helpers):  gsr_backward_blend, gsr_backward_geom,
  *          gsr_sh_grad_from_views, gsr_adam_update_views, gsr_densify_mark, gsr_prune_mark, gsr_split_removal_mask, gsr_mask_scan,
- *          gsr_mask_scan_workspace_bytes, gsr_block_order_ints, gsr_clone_gaussians, gsr_split_gaussians, gsr_compact_gaussians,
+ *          gsr_mask_scan_workspace_bytes, gsr_block_order_ints, gsr_backward_accumulators_offset, gsr_clone_gaussians, gsr_split_gaussians, gsr_compact_gaussians,
  *          gsr_reset_opacities, gsr_init_gaussians, gsr_stage_timing, gsr_stage_sampling, gsr_stage_times  The workspace functions return the bytes this library really uses (the
  * int64 sort keys live in the binning workspace; the backward needs none beyond 16 bytes). */
 #include <stdint.h>
@@ -256,6 +256,7 @@ int gsr_densify_mark(const GsrParams *p, const float *g, int64_t n, float a, flo
 int gsr_prune_mark(const GsrParams *p, float t, int32_t *v, void *s) { (void)p; (void)t; (void)v; (void)s; return GSR_E_HIP; }
 int gsr_split_removal_mask(int64_t n, int64_t o, const int32_t *m, int32_t *v, void *s) { (void)n; (void)o; (void)m; (void)v; (void)s; return GSR_E_HIP; }
 size_t gsr_mask_scan_workspace_bytes(int64_t N) { (void)N; return 256; }
+size_t gsr_backward_accumulators_offset(int64_t N) { (void)N; return 0; } /* the CPU backward keeps no accumulator records: its GsrGrads arrays are all required */
 size_t gsr_block_order_ints(int32_t W, int32_t H) { (void)W; (void)H; return 4; } /* never written or read on the CPU */
 int gsr_mask_scan(int64_t N, const int32_t *m, int32_t *p, int32_t *c, void *s, size_t b, void *st) { (void)N; (void)m; (void)p; (void)c; (void)s; (void)b; (void)st; return GSR_E_HIP; }
 int gsr_clone_gaussians(const GsrParams *i, const int32_t *m, const int32_t *p, float n, const GsrParams *o, void *s) { (void)i; (void)m; (void)p; (void)n; (void)o; (void)s; return GSR_E_HIP; }

@@ -395,9 +395,11 @@ def test_sh_direction_sums_handed_from_forward_to_backward(oracle, cameras, scen
 
 
 def test_backward_accumulators_cleared_by_the_forward(oracle, cameras, scenes):
-    """GsrBinning.backward_ws: the forward blend kernel's spare workgroups clear the backward's accumulators, and the backward()
-    that follows skips its own clear -- once: a second backward() on the same forward, a backward() after another forward's
-    backward, or one with a foreign point_list must clear for itself.  Every one of them has to give the oracle's gradients."""
+    """GsrBinning.backward_ws: the forward blend kernel's spare workgroups clear the accumulators of a backward workspace made for
+    that frame, and the first backward() handed the frame's point_list takes that workspace and skips its own clear -- once: a second
+    backward() on the same forward, or one with a foreign point_list, gets a fresh workspace and clears it.  (Workspaces are per
+    call since ABI 7 -- the returned blend-stage gradients are views of them -- so an older forward's workspace stays valid while a
+    later forward runs.)  Every one of them has to give the oracle's gradients, and earlier returns must not change."""
     import torch
     gsr = pkg()
     from conftest import sub
@@ -410,16 +412,22 @@ def test_backward_accumulators_cleared_by_the_forward(oracle, cameras, scenes):
     dpix = _pixel_grad(160, 192)
     g_ref = oracle.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix))
     buf_a = gsr.render_gaussians(**kw)[2]
-    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_a, dpix)), g_ref)
+    g_a = gsr.backward(**backward_kwargs(sc, cam, kw, buf_a, dpix))
+    parity.compare_backward(g_a, g_ref)
     assert bwd.last_call_skipped_the_clear
+    keep = {k: g_a[k].clone() for k in ("dL_dcolor", "dL_dmean2D", "dL_dconic")}
     parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_a, dpix)), g_ref)      # the same forward again
     assert not bwd.last_call_skipped_the_clear
     buf_b = gsr.render_gaussians(**kw)[2]
-    buf_c = gsr.render_gaussians(**kw)[2]                                                       # clears the workspace again
-    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_b, dpix)), g_ref)      # an older forward's buffers: stale tag
-    assert not bwd.last_call_skipped_the_clear
-    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_c, dpix)), g_ref)      # its own were dirtied by the call above
-    assert not bwd.last_call_skipped_the_clear
+    buf_c = gsr.render_gaussians(**kw)[2]
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_b, dpix)), g_ref)      # an older forward: its own workspace, still clean
+    assert bwd.last_call_skipped_the_clear
+    parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, buf_c, dpix)), g_ref)
+    assert bwd.last_call_skipped_the_clear
+    for k, v in keep.items():                                                                  # the first call's views were not touched by the later calls
+        assert torch.equal(g_a[k], v), k
+    assert g_a["dL_dcolor"]._base is not None and g_a["dL_dmean2D"]._base is g_a["dL_dcolor"]._base and tuple(g_a["dL_dconic"].shape) == (6000, 4)
+    assert float(g_a["dL_dmean2D"][:, 2].abs().max()) == 0.0 and float(g_a["dL_dconic"][:, 2].abs().max()) == 0.0
     parity.compare_backward(gsr.backward(**backward_kwargs(sc, cam, kw, ref[2], dpix)), g_ref)     # the oracle's (numpy) buffers
     assert not bwd.last_call_skipped_the_clear
 
