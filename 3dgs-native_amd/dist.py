@@ -29,15 +29,57 @@ MAX_VIEWS_PER_CALL = 16      # GSR_MAX_VIEWS of include/gsr.h
 def init_from_env(backend=None, device=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # dmabuf IPC is what this pool's host driver supports; RCCL reads the variable when it first opens a peer's memory, so a
-    # rank that did not inherit it (torch.distributed.run does not add it) still gets it here, before the process group exists
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # dmabuf IPC is what this pool's host driver supports.  The ROCr runtime reads HSA_ENABLE_IPC_MODE_LEGACY ONCE, when it
+    # initialises -- i.e. at the process's first HIP call -- so the place to set it is the top of the entry script, before torch is
+    # imported (bench.py, examples/train.py, tests/dist_worker.py and launch.py all do).  Setting it here only helps a rank that
+    # has not touched the GPU yet; one that has, and did not inherit the variable, is told so instead of failing later inside RCCL.
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+        if torch.cuda.is_initialized():
+            import warnings
+            warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY was not set before the HIP runtime started: RCCL's peer-memory sharing may fail "
+                          "with hipIpcGetMemHandle: invalid argument.  Export HSA_ENABLE_IPC_MODE_LEGACY=0 before the first HIP call.")
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend=backend, **kw)
     return dist.get_rank(), dist.get_world_size()
+
+
+class ViewStreams:
+    """Several views per GPU in flight at once (config #4 on fewer GPUs than views).  One view's
+    launch- and latency-bound sort chain leaves most of the chip idle; issued on separate HIP streams, another view's blend
+    kernels fill it (bench.py --views-per-step: 790 -> 935 Mpixels/s at three views in round 1).  The library keeps its scratch
+    per stream, so the calls are independent; results equal the serial ones (float-atomic order aside).
+
+        vs = ViewStreams(3)
+        outs = vs.map(render_and_backward, views)      # outs[i] = fn(views[i]); all work is ordered into the caller's stream
+
+    Item i runs on stream i % k.  Every stream first waits for the caller's stream (so inputs written there -- the parameters an
+    optimizer step just updated -- are seen, and blocks the caching allocator recycles from a previous round are not reused
+    early), and the caller's stream waits for all of them before `map` returns: tensors made inside `fn` may be used on the
+    caller's stream right away."""
+
+    def __init__(self, k, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(k)))]
+
+    def map(self, fn, items):
+        items = list(items)
+        if len(self.streams) == 1 or len(items) <= 1:
+            return [fn(it) for it in items]           # nothing to overlap: stay on the caller's stream
+        main = torch.cuda.current_stream(self.device)
+        used = self.streams[:min(len(self.streams), len(items))]
+        for st in used:
+            st.wait_stream(main)
+        outs = []
+        for i, it in enumerate(items):
+            with torch.cuda.stream(self.streams[i % len(self.streams)]):
+                outs.append(fn(it))
+        for st in used:
+            main.wait_stream(st)
+        return outs
 
 
 def views_for_rank(num_views, rank, world_size):

@@ -353,7 +353,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {'reference initial point set (scale ' + str(cfg['init_scale']) + ')' if 'init_scale' in cfg else 'synthetic'} {W}x{H}, {N} Gaussians, SH degree 3, seed {cfg['seed']}, forward+backward, "
                                f"Lego train pose 0" + (" rotated per rank" if world > 1 else ""),
-                   "width": W, "height": H, "gaussians": N, "visible": Nv, "tile_pairs_D": D, "views_per_step": world * vps,
+                   "width": W, "height": H, "gaussians": N, "visible": Nv, "tile_pairs_D": D, "views_per_step": world * vps, "views_per_gpu": vps,
                    "parallelism": f"dp{world}: {'one view' if vps == 1 else str(vps) + ' views on ' + str(vps) + ' streams'} per GPU, replicated Gaussians" + ((f", {backend_name} all-reduce of the 59-float gradient arena" if args.dense_exchange else
                                                                                         f", {backend_name} all-reduce of 11 floats + all-gather of 3 floats per Gaussian, SH gradient rebuilt per rank") if world > 1 else "")},
         "step_ms": {"median": round(float(np.median(per_step)), 4), "p10": round(float(np.percentile(per_step, 10)), 4),

@@ -127,6 +127,11 @@ def main():
     ap.add_argument("--gaussians", type=int, default=5000)      # reference default (config.py:31)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--views-per-step", type=int, default=1)
+    ap.add_argument("--view-streams", type=int, default=0, help="when a rank has several views per step (--views-per-step beyond the "
+                    "number of GPUs), render up to this many at once on separate HIP streams (1 = one after the other; 0 = decide by "
+                    "scene size each step: 3 from 2^17 Gaussians up -- +9 %% at 1 M Gaussians, profiles/r04_c_views_per_gpu.txt -- and 1 "
+                    "below, where a step is host-bound and the extra stream hand-overs cost more than they hide: 872 against 750 "
+                    "iterations/s at 6 000 Gaussians)")
     ap.add_argument("--size", type=int, default=400)
     ap.add_argument("--densify-from", type=int, default=500)    # train.py:391-394 defaults
     ap.add_argument("--densify-until", type=int, default=15000)
@@ -194,6 +199,8 @@ def main():
     sched = {k: gsr.scheduler.LRScheduler(lr) for k, lr in gsr.optimizer.DEFAULT_LR.items()}
     rng = np.random.default_rng(0)                                          # same stream on every rank -> same view batch
     loss_hist = torch.zeros(max(1, args.iterations), device=dev)            # the loss curve stays on the device until the end
+    per_rank_views = -(-args.views_per_step // world)
+    streams_few, streams_many = gsr.dist.ViewStreams(1, dev), gsr.dist.ViewStreams(min(per_rank_views, args.view_streams or 3), dev)
     density_log = [{"iteration": -1, "points": model.num_points}]
     import time
     torch.cuda.synchronize(dev)
@@ -207,14 +214,13 @@ def main():
         # ranks exchange that (11 + 3 floats per Gaussian instead of 59, dist.py) and the Adam kernel forms basis x payload
         # inside the SH update (optimizer.adam_update(sh_views=...)) -- also with one rank.  --dense-sh keeps the 48-float path.
         factored = not args.dense_sh
-        for v in mine:
+        def one_view(v):
             c = cams[v]
             kw = dict(background=bg, means3D=P["positions"], opacity=P["opacities"], scales=P["scales"], rotations=P["rotations"],
                       viewmatrix=c["world_to_camera"], projmatrix=c["full_proj_matrix"], tan_fovx=c["tan_fovx"], tan_fovy=c["tan_fovy"],
                       image_height=c["height"], image_width=c["width"], sh=P["shs"], degree=3, campos=c["camera_center"])
             img, _, buf = gsr.render_gaussians(**kw)
             loss_sum, dpix = gsr.loss.l1_loss_and_gradients(img, targets[v])
-            loss_acc += loss_sum / (c["height"] * c["width"] * 3)
             g = gsr.backward(background=bg, means3D=P["positions"], dL_dpixels=dpix, opacity=P["opacities"], shs=P["shs"], scales=P["scales"],
                              rotations=P["rotations"], viewmatrix=kw["viewmatrix"], projmatrix=kw["projmatrix"], tan_fovx=kw["tan_fovx"],
                              tan_fovy=kw["tan_fovy"], image_height=c["height"], image_width=c["width"], campos=kw["campos"],
@@ -222,9 +228,16 @@ def main():
                              cov3Ds=buf["cov3Ds"], clamped=buf["clamped_state"], binning_buffer={"point_list": buf["point_list"]},
                              img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]},
                              sh_gradient="factored" if factored else "dense")
-            arena = g["_arena"] if arena is None else arena.add_(g["_arena"])
+            return loss_sum / (c["height"] * c["width"] * 3), g["_arena"], g["_view_payload"]
+
+        # a rank with several views renders them on separate streams (one view's sort chain under another's blend kernels) and
+        # then sums them in view order, exactly as the serial loop does
+        view_streams = streams_many if (args.view_streams > 1 or (args.view_streams == 0 and n >= (1 << 17))) else streams_few
+        for l_v, a_v, p_v in view_streams.map(one_view, mine):
+            loss_acc += l_v
+            arena = a_v if arena is None else arena.add_(a_v)
             if factored:
-                payloads.append(g["_view_payload"])
+                payloads.append(p_v)
         per_rank = -(-len(batch) // world)                                  # views per rank, rounded up
         if factored:
             if arena is None:
