@@ -276,7 +276,9 @@ int gsr_l1_loss_grad(const float *rendered, const float *target, float *pixel_gr
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return GSR_E_HIP;
     const int64_t n = (int64_t)W * H * 3;
-    const unsigned blocks = (unsigned)std::min<int64_t>(2048, gsr_div_up(gsr_div_up(n, 4), 256));
+    // at most two workgroups per CU, grid stride: every workgroup ends with one atomic on the ONE loss word, and 1 875 of them (an
+    // 800 x 800 image at a float4 per thread) queued there for ~20 us behind 6 us of streaming (27.4 -> 8 us in the trainer's trace)
+    const unsigned blocks = (unsigned)std::min<int64_t>(512, gsr_div_up(gsr_div_up(n, 4), 256));
     hipLaunchKernelGGL(l1_loss_grad_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, rendered, target, pixel_grad, loss_sum, n, l1_weight);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_E_HIP;
 }

@@ -9,9 +9,10 @@ import torch
 from . import _host, _lib
 
 
-def l1_loss_and_gradients(rendered, target, lambda_dssim=0.0, want_grad=True):
+def l1_loss_and_gradients(rendered, target, lambda_dssim=0.0, want_grad=True, loss_out=None):
     """One kernel: returns (loss_sum device tensor [1] = sum |rendered - target|, pixel_grad (H,W,3) or None).
-    mean L1 = loss_sum / (H*W*3); pixel_grad = (1-lambda_dssim)/(H*W*3) * sign(rendered - target)."""
+    mean L1 = loss_sum / (H*W*3); pixel_grad = (1-lambda_dssim)/(H*W*3) * sign(rendered - target).
+    `loss_out`: a 1-element float32 device tensor (e.g. a slot of a trainer's loss curve) to receive the sum instead of a fresh one."""
     L = _lib.lib()
     dev = _host.device_of(rendered, target)
     r = _host.to_dev(rendered, torch.float32, dev)
@@ -19,7 +20,9 @@ def l1_loss_and_gradients(rendered, target, lambda_dssim=0.0, want_grad=True):
     r = r.reshape(H, W, 3)
     t = _host.to_dev(target, torch.float32, dev, (H, W, 3))   # alpha already dropped by the caller (train.py:323-334)
     grad = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if want_grad else None
-    loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+    if loss_out is not None and not (isinstance(loss_out, torch.Tensor) and loss_out.is_cuda and loss_out.dtype == torch.float32 and loss_out.numel() == 1):
+        raise ValueError("l1_loss_and_gradients: loss_out must be a 1-element float32 device tensor")
+    loss_sum = torch.empty(1, dtype=torch.float32, device=dev) if loss_out is None else loss_out
     l1_weight = (1.0 - float(lambda_dssim)) / (H * W * 3.0)
     with torch.cuda.device(dev):
         _lib.check(L.gsr_l1_loss_grad(_host.ptr(r), _host.ptr(t), _host.ptr(grad), _host.ptr(loss_sum), W, H, l1_weight,

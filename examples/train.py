@@ -200,6 +200,7 @@ def main():
     rng = np.random.default_rng(0)                                          # same stream on every rank -> same view batch
     loss_hist = torch.zeros(max(1, args.iterations), device=dev)            # the loss curve stays on the device until the end
     per_rank_views = -(-args.views_per_step // world)
+    sum_scale = float(cams[0]["height"] * cams[0]["width"] * 3)             # an L1 sum -> mean (all views of a dataset share one size)
     streams_few, streams_many = gsr.dist.ViewStreams(1, dev), gsr.dist.ViewStreams(min(per_rank_views, args.view_streams or 3), dev)
     density_log = [{"iteration": -1, "points": model.num_points}]
     import time
@@ -209,7 +210,7 @@ def main():
         P, M, V, n = model.params, model.adam_m, model.adam_v, model.num_points
         batch = rng.choice(len(cams), size=args.views_per_step, replace=False)
         mine = [int(batch[i]) for i in gsr.dist.views_for_rank(len(batch), rank, world)]
-        arena, loss_acc, payloads = None, torch.zeros(1, device=dev), []
+        arena, loss_acc, payloads = None, (torch.zeros(1, device=dev) if len(mine) > 1 else None), []
         # The SH gradient is never materialised: backward() returns the 3-float view payload it is an outer product of, the
         # ranks exchange that (11 + 3 floats per Gaussian instead of 59, dist.py) and the Adam kernel forms basis x payload
         # inside the SH update (optimizer.adam_update(sh_views=...)) -- also with one rank.  --dense-sh keeps the 48-float path.
@@ -220,7 +221,8 @@ def main():
                       viewmatrix=c["world_to_camera"], projmatrix=c["full_proj_matrix"], tan_fovx=c["tan_fovx"], tan_fovy=c["tan_fovy"],
                       image_height=c["height"], image_width=c["width"], sh=P["shs"], degree=3, campos=c["camera_center"])
             img, _, buf = gsr.render_gaussians(**kw)
-            loss_sum, dpix = gsr.loss.l1_loss_and_gradients(img, targets[v])
+            # (one view per rank and step: the L1 sum goes straight into this iteration's slot of the loss curve)
+            loss_sum, dpix = gsr.loss.l1_loss_and_gradients(img, targets[v], loss_out=loss_hist[it:it + 1] if len(mine) == 1 else None)
             g = gsr.backward(background=bg, means3D=P["positions"], dL_dpixels=dpix, opacity=P["opacities"], shs=P["shs"], scales=P["scales"],
                              rotations=P["rotations"], viewmatrix=kw["viewmatrix"], projmatrix=kw["projmatrix"], tan_fovx=kw["tan_fovx"],
                              tan_fovy=kw["tan_fovy"], image_height=c["height"], image_width=c["width"], campos=kw["campos"],
@@ -228,13 +230,14 @@ def main():
                              cov3Ds=buf["cov3Ds"], clamped=buf["clamped_state"], binning_buffer={"point_list": buf["point_list"]},
                              img_buffer={"ranges": buf["ranges"], "final_Ts": buf["final_Ts"], "n_contrib": buf["n_contrib"]},
                              sh_gradient="factored" if factored else "dense")
-            return loss_sum / (c["height"] * c["width"] * 3), g["_arena"], g["_view_payload"]
+            return (loss_sum if len(mine) == 1 else loss_sum / (c["height"] * c["width"] * 3)), g["_arena"], g["_view_payload"]
 
         # a rank with several views renders them on separate streams (one view's sort chain under another's blend kernels) and
         # then sums them in view order, exactly as the serial loop does
         view_streams = streams_many if (args.view_streams > 1 or (args.view_streams == 0 and n >= (1 << 17))) else streams_few
         for l_v, a_v, p_v in view_streams.map(one_view, mine):
-            loss_acc += l_v
+            if len(mine) > 1:
+                loss_acc += l_v
             arena = a_v if arena is None else arena.add_(a_v)
             if factored:
                 payloads.append(p_v)
@@ -244,24 +247,34 @@ def main():
                 arena = torch.zeros(gsr.dist.arena_size(n, small=True), device=dev)
             while len(payloads) < per_rank:                                 # ranks with a view less gather a zero payload
                 payloads.append(torch.zeros(3 * n + 4, device=dev))
-            arena.mul_(world / len(batch))                                  # mean over the batch after the /world of the average
-            gathered = gsr.dist.exchange_factored(arena, torch.stack(payloads).view(-1), average=True)
+            if world != len(batch):
+                arena.mul_(world / len(batch))                              # mean over the batch after the /world of the average
+            if world == 1:
+                sh_views = payloads                                         # nothing to exchange: the Adam kernel takes the list as it is
+            else:
+                sh_views = gsr.dist.exchange_factored(arena, torch.stack(payloads).view(-1), average=True).view(world * per_rank, 3 * n + 4)
             grads = gsr.dist.small_arena_views(arena, n)
             grads["dL_dshs"] = None
-            sh_views, sh_scale = gathered.view(world * per_rank, 3 * n + 4), 1.0 / len(batch)
-            if sh_views.shape[0] > gsr.dist.MAX_VIEWS_PER_CALL:             # more views than one kernel call takes: rebuild in chunks
-                grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(P["positions"], sh_views, 3, scale=sh_scale)
+            sh_scale = 1.0 / len(batch)
+            if len(sh_views) > gsr.dist.MAX_VIEWS_PER_CALL:                 # more views than one kernel call takes: rebuild in chunks
+                grads["dL_dshs"] = gsr.dist.sh_gradients_from_views(P["positions"], torch.stack(list(sh_views)), 3, scale=sh_scale)
                 sh_views, sh_scale = None, None
         else:
             if arena is None:
                 arena = torch.zeros(gsr.dist.arena_size(n), device=dev)
-            arena.mul_(1.0 / max(1, len(batch)))
-            grads = gsr.dist.arena_views(arena, n)
+            if world != len(batch):
+                arena.mul_(world / len(batch))                              # mean over the batch after the /world of the average
+            if world > 1:
+                gsr.dist.reduce_gradients(arena, world, average=True)       # (this all-reduce was missing before round 4: --dense-sh
+            grads = gsr.dist.arena_views(arena, n)                          #  with several ranks trained every rank on its own views only)
             sh_views, sh_scale = None, None
         lrs = {k: s.get_lr(it, args.iterations) for k, s in sched.items()}
         model.grads = gsr.optimizer.grads_from_backward(grads)              # train.py:1047-1051
         gsr.optimizer.adam_update(P, model.grads, M, V, lrs, iteration=it, sh_views=sh_views, sh_degree=3, sh_scale=sh_scale)
-        loss_hist[it] = loss_acc[0] / max(1, len(mine))
+        if len(mine) > 1:
+            loss_hist[it] = loss_acc[0] / len(mine)
+        elif len(mine) == 1:
+            pass                                                            # written by the loss kernel as a SUM: scaled once, at the end
         log = model.densification_and_pruning(it)                           # train.py:1060
         if log["cloned"] or log["split"] or log["pruned"] or log["opacity_reset"] or log["prune_skipped"]:
             density_log.append({"iteration": it, "cloned": log["cloned"], "split": log["split"], "split_removed": log["split_removed"],
@@ -273,9 +286,12 @@ def main():
         if rank == 0 and args.output and (it % args.save_interval == 0 or it == args.iterations - 1):
             gsr.point_cloud.save_ply(model.params, os.path.join(args.output, "point_cloud", f"iteration_{it}", "point_cloud.ply"), model.num_points)
         if rank == 0 and (it % args.print_interval == 0 or it == args.iterations - 1):
-            print(f"iter {it:5d}  loss {float(loss_acc.item()) / max(1, len(mine)):.6f}", flush=True)
+            shown = float(loss_hist[it].item()) / (sum_scale if len(mine) == 1 else 1.0)
+            print(f"iter {it:5d}  loss {shown:.6f}", flush=True)
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t_start
+    if per_rank_views == 1:
+        loss_hist /= sum_scale                                              # slots hold sums of |difference|: one division for the whole curve
     if rank == 0:
         finish(args, model, cams, targets, bg, loss_hist, density_log, wall, dev)
 
