@@ -122,6 +122,27 @@ __device__ __forceinline__ float half_scan_add(float v)
         : "+v"(v));
     return v;
 }
+// ... and over each 16-lane DPP row separately (four pixels per step): the four row_shr steps alone
+__device__ __forceinline__ float row_scan_mul(float v)
+{
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float row_scan_add(float v)
+{
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ int wave_max_i(int v)
 {
 #pragma unroll
@@ -182,6 +203,24 @@ __device__ __forceinline__ float power_ref_order(float ca2, float cb2, float tc,
 #define GSR_FILL_K 4
 #endif
 constexpr int FILL_K = GSR_FILL_K;
+// GSR_BWD_BUCKET: entries per bucket -- 32 (the product), 64 (rounds 2-3) or 16.  A bucket of at most 32 entries runs TWO pixels per
+// step (each 32-lane half holds the bucket against its own pixel; scans of five DPP steps instead of six), one of at most 16
+// FOUR (GSR_BWD_FOUR: 16-lane rows, four-step scans) -- the "16-entry x 4-pixel lane layout" of round 3's notes, here as the form
+// the LAST bucket of a block takes.  Fewer scan steps per (entry, pixel) pair against more buckets (record gather, LDS transpose,
+// flush per bucket).  Round 4, rocprofv3 kernel averages over 60 launches, three interleaved runs per build on one box
+// (profiles/r04_d_bwd_bucket_kernel_averages.txt -- the kernel's run-to-run spread is +-4 %, so single A/B pairs mislead):
+//   C3: 64 -> 150.5 us, 32 -> 147.0, 32 + four-pixel last bucket + skipped finished pixel pairs -> 142.4 (lowest in every run);
+//   C0: 64 -> 226.0, 32 -> 219.0;  16 throughout (four pixels everywhere): C3 145.6, C0 233.6, C5 406 against 414 / 410 (tools/ab.sh).
+#ifndef GSR_BWD_BUCKET
+#define GSR_BWD_BUCKET 32
+#endif
+#ifndef GSR_BWD_FOUR
+#define GSR_BWD_FOUR 1      // 1: a bucket of at most 16 entries runs four pixels per step (16-lane rows, four-step scans)
+#endif
+#ifndef GSR_BWD_SKIP2
+#define GSR_BWD_SKIP2 1     // 1: the two-pixel form skips a step when both pixels' replays have ended
+#endif
+constexpr int BUCKET = GSR_BWD_BUCKET;
 constexpr int QCAP = 128;                 // ring of compacted entries (power of two, >= 63 + 64): a chunk is consumed only while it fits
 
 // USE_MASKS: the per-block hit masks the forward wrote (GsrBinning.block_masks) replace the compaction's own test.  They are
@@ -298,10 +337,11 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
 
     int cursor = hi_all; // next list index (exclusive) to pull candidates from, moving towards `start`
     int head = 0, qn = 0; // ring state (wave-uniform)
+    constexpr int bucket = BUCKET; // entries per bucket (see GSR_BWD_BUCKET above)
     TL(0) // prologue
     for (;;) {
         // ---- fill: pull candidates (deepest first) until a full bucket is queued or the list is exhausted ----
-        while (qn < 64 && cursor > start) {
+        while (qn < bucket && cursor > start) {
             if (USE_MASKS) {
                 // The forward already tested every staged entry against the tile's eight 8x4 blocks (blend_fwd.hip): one byte
                 // per entry, read coalesced, instead of two 16-byte gathers and the convex test per candidate.  FILL_K chunks of
@@ -353,11 +393,12 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         TL(1) // fill
 
         // ---- one bucket: lane k takes the k-th queued entry (still deepest first) ----
-        const int n = min(64, qn);
+        const int n = min(bucket, qn);
         // A bucket of at most 32 entries (every block's last one, half of the time) runs TWO pixels per step: lanes 0-31 hold
         // the entries against pixel 2s, lanes 32-63 the same entries against pixel 2s + 1, and the scans stay inside each half.
-        const bool two = n <= 32 && (NPIX % 2 == 0);
-        const int elane = two ? (lane & 31) : lane; // which entry of the bucket this lane holds
+        const bool four = n <= 16 && BW % 4 == 0 && GSR_BWD_FOUR; // ... and one of at most 16 FOUR pixels per step, a 16-lane row each
+        const bool two = !four && n <= 32 && (NPIX % 2 == 0);
+        const int elane = four ? (lane & 15) : two ? (lane & 31) : lane; // which entry of the bucket this lane holds
         const bool valid = elane < n;
         const int slot = (head + elane) & (QCAP - 1);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -420,7 +461,28 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         }                                                                                                                     \
     }
         const int rows_run = GSR_ABL(dbg, 2) ? 1 : BH;
-        if (!two) {
+        if (four) {
+            const int sub = lane >> 4;
+            for (int r = 0; r < rows_run; ++r) {
+                const float d_y = a.y - (fy0 + (float)r), tc = row_term(cc2, d_y);
+                for (int q4 = r * BW; q4 < (GSR_ABL(dbg, 2) ? 4 : (r + 1) * BW); q4 += 4) {
+                    const int q = q4 + sub;
+                    const float4 pb = s_pb[q];
+                    const int pkept = __float_as_int(pb.w);
+                    if (__ballot(pkept > idx_min) == 0ull) continue; // all four pixels' replays end before every entry of the bucket
+                    TL_COUNT(7, 1ull)
+                    GSR_PIXEL_STEP(q, row_scan_mul, row_scan_add, (lane & 15) == 15)
+                }
+            }
+            // an entry's sums are split over its four lanes (one per row): add them up (rows 1-3 then hold copies and stay out of the flush)
+#define GSR_SUM4(v) v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            GSR_SUM4(g_c0) GSR_SUM4(g_c1) GSR_SUM4(g_c2) GSR_SUM4(S1) GSR_SUM4(S2) GSR_SUM4(Sxx) GSR_SUM4(Sxy) GSR_SUM4(Syy) GSR_SUM4(Sop)
+#undef GSR_SUM4
+            int t4 = (int)touched;
+            t4 |= __shfl_xor(t4, 16, 64);
+            t4 |= __shfl_xor(t4, 32, 64);
+            touched = t4 != 0 && lane < 16;
+        } else if (!two) {
             for (int r = 0; r < rows_run; ++r) {
                 const float d_y = a.y - (fy0 + (float)r), tc = row_term(cc2, d_y);
                 for (int q = r * BW; q < (GSR_ABL(dbg, 2) ? 1 : (r + 1) * BW); ++q) {
@@ -439,6 +501,9 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
                     const int q = q2 + sub;
                     const float4 pb = s_pb[q];
                     const int pkept = __float_as_int(pb.w);
+#if GSR_BWD_SKIP2
+                    if (__ballot(pkept > idx_min) == 0ull) continue; // both pixels' replays end before every entry of the bucket
+#endif
                     TL_COUNT(7, 1ull)
                     GSR_PIXEL_STEP(q, half_scan_mul, half_scan_add, (lane & 31) == 31)
                 }
@@ -464,8 +529,9 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
         s_g[lane][5] = g_ca; s_g[lane][6] = g_cb; s_g[lane][7] = g_cc; s_g[lane][8] = g_op;
         __syncthreads();
         const int c = lane & 15, fslot = gsr_gradrec_slot(c); // the record's layout leaves the API arrays' zero columns free
+        const int flush_rows = (n + 3) >> 2; // four entries per wave instruction; entries beyond n have nothing
 #pragma unroll 4
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < flush_rows; ++r) {
             const int e = r * 4 + (lane >> 4);
             const int eid = s_id[e];
             if (c < 9 && eid >= 0 && !GSR_ABL(dbg, 1)) unsafeAtomicAdd(&acc[eid].f[fslot], s_g[e][c]);
