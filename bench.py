@@ -421,7 +421,7 @@ def main():
             # SURVEY section 8(d)'s courtesy figure: the same restatement over all host cores (bands of Gaussians / of tile rows in
             # threads; per-thread gradient accumulators summed afterwards).  Not how the reference's CPU path runs (Warp's CPU device
             # is one serial loop) and not the baseline: reported beside it.
-            T = max(1, min(os.cpu_count() or 1, 64))
+            T = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))   # the cores this process may use
             t0 = time.perf_counter()
             pi, pd, pb = oracle.render_gaussians(**okw, threads=T)
             pgeom = {"radii": pb["radii"], "means2D": pb["points_xy_image"], "conic_opacity": pb["conic_opacity"], "rgb": pb["colors"],
