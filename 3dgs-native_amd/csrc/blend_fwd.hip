@@ -20,6 +20,11 @@
 // which some pixel would saturate takes the masked path.  `n_contrib` is the 1-based LIST position of the last contributing
 // entry, so skipping dead entries does not change it.
 //
+// Round 4: a wave whose 64 pixels have all saturated leaves the workgroup instead of serving the tile's barriers until its slowest
+// block is done (s_barrier waits for surviving waves only), and the batch shrinks to 64 entries per surviving wave: its wave slot
+// goes to the next tile's workgroup that much earlier (103.5 against 105.4 us at C3, 229 against 234 at C5; rocprofv3 averages of
+// three interleaved runs, profiles/r04_e_fwd_early_exit_kernel_averages.txt).
+//
 // Measured and rejected in round 2: eight waves per tile, each blending TWO entries per instruction over an 8x4 block
 // (v_permlane32_swap hand-over of 1 - alpha): bit-identical results, but splats at C3 are as large as the blocks, so the finer
 // blocks cull almost nothing (168 live entries per 8x4 block against 168 per 8x8 block) and the pair step costs 28 vector
@@ -190,7 +195,17 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     if (tid < 3) reinterpret_cast<float4 *>(s_rec + BATCH * REC_BYTES)[tid] = make_float4(0.f, 0.f, 0.f, 0.f); // the sentinel
 
     TL_DECL
-    // software pipeline: the gather of batch k+1 (id, then its 64-byte record) is in flight while batch k is blended
+    // A wave whose 64 pixels have all saturated LEAVES (s_barrier waits for the surviving waves of a workgroup only --
+    // tools/barrier_exit_probe.hip), instead of serving the tile's barriers until its slowest block is done: its wave slot is free
+    // for the next tile's workgroup that much earlier.  The batch is then 64 entries per surviving wave.  Who stages what is agreed
+    // one batch ahead: `alive_cur` (the set this batch was prefetched under) and `alive_next` (s_alive as every wave reads it
+    // behind the top barrier, i.e. after the leavers of the last walk cleared their bits).  A leaver still stages its share of
+    // the batch that was prefetched with it, then goes: the others' next wait for it falls under their walk of that batch.
+    __shared__ int s_alive;
+    if (tid == 0) s_alive = 0xF;
+    int alive_cur = 0xF;
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv); // wave-uniform copy: the bookkeeping below stays in scalar registers
+    auto rank_in = [&](int set) { return __popc(set & ((1 << wv_u) - 1)); };
     int nid = (start + tid < end) ? point_list[start + tid] : -1;
     float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
     float2 ncd = make_float2(0.f, 0.f);
@@ -199,48 +214,27 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         na = rp[0]; nb = rp[1];
         ncd = *reinterpret_cast<const float2 *>(rp + 2);
     }
-#ifdef GSR_FWD_COUNT_INLINE
-    // block filing without re-reading the masks: per 8x4 block of this wave (A = rows 0-3 = lanes 0-31, B = rows 4-7), the mask
-    // hits of every batch walked so far (scalar: two more ballots per 64 entries of the list build) and their value at the end of
-    // the last batch in which one of the block's pixels took a contribution
-    int cum_a = 0, cum_b = 0, kept_a = 0, kept_b = 0;
-    const int bit_a = 1 << ((wv >> 1) * 4 + (wv & 1)), bit_b = bit_a << 2;
-#endif
-#ifdef GSR_FWD_PRIO
-    int bidx = 0;
-#endif
-    for (int base = start; base < end; base += BATCH) {
-        if (__syncthreads_and(done)) break; // whole tile saturated (also fences LDS reuse)
-        TL(0) // top barrier (first time: launch -> here)
-#ifdef GSR_FWD_PRIO
-        // a wave deep in its list is one of the long-lived ones that decide when the kernel ends: it goes first
-        { const int pr = bidx >> GSR_FWD_PRIO; ++bidx;
-          if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr >= 3) __builtin_amdgcn_s_setprio(3); }
-#endif
-
-        const int cnt = min(BATCH, end - base);
-#ifdef GSR_TIMELINE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TL(1) // waiting for the gathered records
-#endif
-        if (tid < cnt) {
+    for (int base = start; base < end;) {
+        __syncthreads(); // every surviving wave has walked the last batch (LDS reuse) and the leavers' bits are cleared
+        TL(0)
+        const int alive_next = __builtin_amdgcn_readfirstlane(s_alive);
+        if (alive_next == 0) break; // the last block saturated: nothing left to blend in this tile
+        const int cnt = min(64 * __popc(alive_cur), end - base);
+        const int e = 64 * rank_in(alive_cur) + lane; // my entry of this batch
+        if (e < cnt) {
             const float4 a = na, b = nb;
-            float4 *dst = reinterpret_cast<float4 *>(s_rec + tid * REC_BYTES);
+            float4 *dst = reinterpret_cast<float4 *>(s_rec + e * REC_BYTES);
             dst[0] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
             dst[1] = make_float4(-0.5f * b.x, b.y, b.z, b.w);
             *reinterpret_cast<float2 *>(dst + 2) = ncd;
             int m = 0;
             if (b.y * 255.0f >= 1.0f) {
-                const float lim = __builtin_amdgcn_logf(b.y * 255.0f) * 0.6931471805599453f * 1.0001f + 1e-3f; // ln via v_log_f32, argument >= 1
-                // axis-aligned box of the ellipse q <= lim (half-widths sqrt(2 lim c / det), sqrt(2 lim a / det), padded): a block
-                // outside it cannot be hit, and only the blocks inside get the exact rectangle test
+                const float lim = __builtin_amdgcn_logf(b.y * 255.0f) * 0.6931471805599453f * 1.0001f + 1e-3f;
                 const float det = a.z * b.x - a.w * a.w;
-                const bool boxless = !(det > 0.0f); // not a proper ellipse (never for a valid conic): exact tests for every block
+                const bool boxless = !(det > 0.0f);
                 const float kdet = 2.0f * lim * fast_rcp(det);
                 const float hx = __builtin_amdgcn_sqrtf(kdet * b.x) * 1.001f + 0.05f, hy = __builtin_amdgcn_sqrtf(kdet * a.z) * 1.001f + 0.05f;
-                const float lx = a.x - hx - tx0, rx = a.x + hx - tx0, ly = a.y - hy - ty0, ry = a.y + hy - ty0; // box relative to the tile origin
-                // candidate blocks = those the box overlaps; the exact test runs once per candidate (most splats have one to four), the
-                // loop's trip count being the largest candidate count among the wave's 64 entries
+                const float lx = a.x - hx - tx0, rx = a.x + hx - tx0, ly = a.y - hy - ty0, ry = a.y + hy - ty0;
                 int cand;
                 {
                     const int xm = (boxless || (lx <= 7.0f && rx >= 0.0f) ? 0x55 : 0) | (boxless || (lx <= 15.0f && rx >= 8.0f) ? 0xAA : 0);
@@ -257,14 +251,14 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
                     if (block_may_hit(a.x, a.y, a.z, a.w, b.x, nb_rc, nb_ra, lim, tx0 + (float)((k & 1) * 8), ty0 + (float)((k >> 1) * 4))) m |= 1 << k;
                 }
             }
-            s_mask[tid] = (uint8_t)m;
-            if (block_masks) block_masks[base + tid] = (uint8_t)m; // for the backward's compaction: one byte per staged entry
+            s_mask[e] = (uint8_t)m;
+            if (block_masks) block_masks[base + e] = (uint8_t)m;
         }
-        TL(2) // staging: LDS image + masks
-        // issue the next batch's gather now; it completes under the blend loop below
-        {
-            const int nidx = base + BATCH + tid;
-            nid = (nidx < end) ? point_list[nidx] : -1;
+        TL(2)
+        const bool staying = (alive_next >> wv_u) & 1;
+        if (staying) { // my share of the next batch, as the next batch's stagers will be
+            const int nidx = base + cnt + 64 * rank_in(alive_next) + lane;
+            nid = (nidx < min(end, base + cnt + 64 * __popc(alive_next))) ? point_list[nidx] : -1;
             if (nid >= 0) {
                 const float4 *rp = reinterpret_cast<const float4 *>(rec + nid);
                 na = rp[0]; nb = rp[1];
@@ -272,10 +266,8 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             }
         }
         __syncthreads();
-        TL(3) // staging barrier
-
-        if (__all(done)) continue; // this wave has nothing left; keep serving the barriers
-
+        TL(3)
+        if (!staying) break; // I cleared my bit after my last walk; my share of this batch is staged: gone
         // this wave's live entries of the batch, compacted in list order (LDS operations of one wave execute in order, so the
         // list can be read back without a barrier); sentinels behind it
         int n = 0;
@@ -283,10 +275,6 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
             const int mv = (g + lane < cnt) ? (int)s_mask[g + lane] : 0;
             const bool hit = (mv & my_bits) != 0;
             const unsigned long long bits = __ballot(hit);
-#ifdef GSR_FWD_COUNT_INLINE
-            cum_a += __popcll(__ballot((mv & bit_a) != 0));
-            cum_b += __popcll(__ballot((mv & bit_b) != 0));
-#endif
             if (hit) s_list[wv][n + __popcll(bits & lt_mask)] = (uint16_t)((g + lane) * REC_BYTES);
             n += __popcll(bits);
         }
@@ -355,16 +343,13 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         // n_contrib = 1-based list position of the last contributing entry: offset / 48 by multiply-shift (exact below 2^16)
         if (last_off >= 0) last = base - start + (int)(((unsigned)last_off * 43691u) >> 21) + 1;
         done = pixf_x == PARKED_X;
-#ifdef GSR_FWD_COUNT_INLINE
-        {
-            const unsigned long long took = __ballot(last_off >= 0);
-            if ((unsigned)took) kept_a = cum_a;
-            if ((unsigned)(took >> 32)) kept_b = cum_b;
+        TL(5)
+        base += cnt;
+        alive_cur = alive_next;
+        if (__all(done) && base < end) {
+            if (lane == 0) atomicAnd(&s_alive, ~(1 << wv_u)); // the next top barrier is behind this
         }
-#endif
-        TL(5) // list walk
     }
-
     if (pix_x < W && pix_y < H) {
         const size_t px = (size_t)pix_y * W + pix_x;
         final_T[px] = T;
@@ -374,18 +359,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         image[3 * px + 2] = cb + T * bg2;
         inv_depth[px] = cd;
     }
-#ifdef GSR_FWD_COUNT_INLINE
-    if (block_order && (lane & 31) == 0) {
-        const int hits = lane ? kept_b : kept_a;
-        const int blk = (wv >> 1) * 4 + (wv & 1) + ((lane >> 5) << 1);
-        const int tpb = (n_tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS, band = tile / tpb;
-        const int q = (band * GSR_BO_CLASSES + gsr_bo_class(hits)) * GSR_BO_SHARDS + ((tile - band * tpb) & (GSR_BO_SHARDS - 1));
-        const int pos = atomicAdd(&block_order[q], 1);
-        if (pos < bo_cap) block_order[GSR_BO_HEADER + (size_t)q * bo_cap + pos] = tile * 8 + blk;
-    }
-#else
     if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, tile, start, last);
-#endif
     TL(6)
     TL_FLUSH
 }
