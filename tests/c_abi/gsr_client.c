@@ -54,11 +54,24 @@ static void dump(FILE *f, const void *d, size_t bytes)
     fwrite(h, 1, bytes, f);
     free(h);
 }
+/* columns [c0, c0 + nc) of n rows of 16 floats in device memory, written packed */
+static void dump_cols(FILE *f, const void *rows, size_t n, int c0, int nc)
+{
+    float *h = malloc(64 * (n ? n : 1));
+    if (n && hipMemcpy(h, rows, 64 * n, hipMemcpyDeviceToHost) != hipSuccess) exit(6);
+    for (size_t i = 0; i < n; ++i) fwrite(h + 16 * i + c0, 4, (size_t)nc, f);
+    free(h);
+}
 #endif
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 1; }
+    /* third argument "records" (HIP build only, ABI 7): xy / conic_opacity / rgb are not given to the forward at all -- it keeps its
+     * blend records in a buffer of ours and we read the three arrays back as its columns; likewise dL_dcolor / dL_dmean2D / dL_dconic
+     * are not given to the backward and are read back as columns of the accumulator records in the backward workspace.  The dump has
+     * the same layout either way, so the two modes can be diffed. */
+    const int records_mode = argc == 4 && strcmp(argv[3], "records") == 0;
+    if (argc != 3 && !records_mode) { fprintf(stderr, "usage: %s in.bin out.bin [records]\n", argv[0]); return 1; }
     FILE *in = fopen(argv[1], "rb");
     if (!in) return 1;
     int64_t N; int32_t hdr[6]; GsrCamera cam;
@@ -81,6 +94,8 @@ int main(int argc, char **argv)
     g.depths = dev_alloc(4 * n); g.cov3D = dev_alloc(24 * n); g.rgb = dev_alloc(12 * n); g.conic_opacity = dev_alloc(16 * n);
     g.clamped_state = dev_alloc(12 * n);
 #ifndef GSR_CLIENT_CPU
+    void *records = NULL;
+    if (records_mode) { records = dev_alloc(64 * n); g.blend_records = records; g.xy = g.rgb = g.conic_opacity = NULL; }
     g.sh_dir_grad = dev_alloc(36 * n); /* forward -> backward: the SH backward then skips the 192-byte coefficient rows */
 #endif
     const size_t geom_bytes = gsr_geom_workspace_bytes(N);
@@ -104,7 +119,8 @@ int main(int argc, char **argv)
     GsrGrads gr = {dev_alloc(12 * n), dev_alloc(12 * n), dev_alloc(16 * n), dev_alloc(4 * n), dev_alloc(192 * n), dev_alloc(12 * n),
                    dev_alloc(12 * n), dev_alloc(16 * n), NULL};
 #ifndef GSR_CLIENT_CPU
-    g.blend_records = geom_ws; /* still untouched: the backward reuses the forward's records */
+    if (records_mode) gr.dL_dcolor = gr.dL_dmean2D = gr.dL_dconic = NULL; /* read back below as columns of the accumulator records */
+    else g.blend_records = geom_ws; /* still untouched: the backward reuses the forward's records */
     bin.backward_ws_cleared = 1; /* ... and bwd_ws has not been touched since gsr_forward_render cleared its accumulators */
 #endif
     CHECK_GSR(gsr_backward(&sc, &cam, &g, &bin, &img, dpix, &gr, bwd_ws, bwd_bytes, stream));
@@ -113,12 +129,27 @@ int main(int argc, char **argv)
     FILE *out = fopen(argv[2], "wb");
     if (!out) return 1;
     fwrite(&D, 8, 1, out);
+#ifndef GSR_CLIENT_CPU
+    if (records_mode) {
+        dump(out, g.radii, 4 * n); dump(out, g.point_offsets, 4 * n); dump_cols(out, records, n, 0, 2); dump(out, g.depths, 4 * n);
+        dump(out, g.cov3D, 24 * n); dump_cols(out, records, n, 6, 3); dump_cols(out, records, n, 2, 4); dump(out, g.clamped_state, 12 * n);
+    } else
+#endif
+    {
     dump(out, g.radii, 4 * n); dump(out, g.point_offsets, 4 * n); dump(out, g.xy, 8 * n); dump(out, g.depths, 4 * n);
     dump(out, g.cov3D, 24 * n); dump(out, g.rgb, 12 * n); dump(out, g.conic_opacity, 16 * n); dump(out, g.clamped_state, 12 * n);
+    }
     dump(out, bin.point_list, 4 * (size_t)D); dump(out, bin.ranges, 8 * (size_t)tiles);
     dump(out, img.image, 12 * P); dump(out, img.inv_depth, 4 * P); dump(out, img.final_T, 4 * P); dump(out, img.n_contrib, 4 * P);
     dump(out, gr.dL_dmean3D, 12 * n); dump(out, gr.dL_dscale, 12 * n); dump(out, gr.dL_drot, 16 * n); dump(out, gr.dL_dopacity, 4 * n);
-    dump(out, gr.dL_dshs, 192 * n); dump(out, gr.dL_dcolor, 12 * n); dump(out, gr.dL_dmean2D, 12 * n); dump(out, gr.dL_dconic, 16 * n);
+    dump(out, gr.dL_dshs, 192 * n);
+#ifndef GSR_CLIENT_CPU
+    if (records_mode) {
+        const char *acc = (const char *)bwd_ws + gsr_backward_accumulators_offset(N);
+        dump_cols(out, acc, n, 0, 3); dump_cols(out, acc, n, 3, 3); dump_cols(out, acc, n, 6, 4);
+    } else
+#endif
+    { dump(out, gr.dL_dcolor, 12 * n); dump(out, gr.dL_dmean2D, 12 * n); dump(out, gr.dL_dconic, 16 * n); }
     fclose(out);
     printf("gsr_client ok: N=%lld D=%lld %dx%d\n", (long long)N, (long long)D, W, H);
     return 0;

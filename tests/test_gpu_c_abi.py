@@ -22,18 +22,18 @@ def _client(name="gsr_client"):
     return exe
 
 
-def run_client(exe, scene, kw, dpix, W, H, n, tmp_path, degree=3):
+def run_client(exe, scene, kw, dpix, W, H, n, tmp_path, degree=3, mode=None):
     """Write the flat input file, run the plain-C client, parse its flat output: (image, inv_depth, buffers, grads)."""
     _host = sub("_host")
     cstruct = _host.make_camera(kw["viewmatrix"], kw["projmatrix"], kw["campos"], kw["background"], kw["tan_fovx"], kw["tan_fovy"], W, H)
     f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32)).tobytes()
-    tag = os.path.basename(exe)
+    tag = os.path.basename(exe) + ("_" + mode if mode else "")
     with open(tmp_path / f"in_{tag}.bin", "wb") as f:
         f.write(np.int64(n).tobytes() + np.array([W, H, degree, 0, 0, 0], np.int32).tobytes() + bytes(cstruct))
         for k in ("means", "scales", "rotations", "opacities", "shs"):
             f.write(f32(scene[k]))
         f.write(f32(dpix))
-    r = subprocess.run([exe, str(tmp_path / f"in_{tag}.bin"), str(tmp_path / f"out_{tag}.bin")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(tmp_path / f"in_{tag}.bin"), str(tmp_path / f"out_{tag}.bin")] + ([mode] if mode else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     blob = open(tmp_path / f"out_{tag}.bin", "rb").read()
     D = int(np.frombuffer(blob, np.int64, 1)[0])
@@ -96,3 +96,26 @@ def test_same_client_against_both_libraries(cameras, scenes, tmp_path):
         assert gb[k].tobytes() == cb[k].tobytes(), k                      # byte for byte
     parity.compare_forward((gi, gd, gb), (ci, cd, cb))
     parity.compare_backward(gg, cg)
+
+
+def test_records_only_mode_through_the_c_abi(oracle, cameras, scenes, tmp_path):
+    """ABI 7 from plain C: the forward is given a record buffer and NO xy / conic_opacity / rgb arrays, the backward NO dL_dcolor /
+    dL_dmean2D / dL_dconic arrays; the client reads all six back as columns of the blend records and of the accumulator records
+    (gsr_backward_accumulators_offset) and writes them in the usual dump layout.  Against the same client with packed arrays: every
+    forward output byte for byte (the same kernels wrote the same values, only elsewhere), gradients under tests/parity.py (float
+    atomics), and both against the oracle."""
+    W, H, n = 192, 144, 4000
+    scene = scenes.synthetic_scene(n, 0.04, 0.6, seed=57)
+    cam = lego_camera(cameras, frame=1, width=W, height=H)
+    kw = render_kwargs(scene, cam, width=W, height=H)
+    dpix = (np.random.default_rng(9).normal(0.0, 1.0, (H, W, 3)) / (H * W * 3)).astype(np.float32)
+    pi, pd, pb, pg = run_client(_client(), scene, kw, dpix, W, H, n, tmp_path)
+    ri, rd, rb, rg = run_client(_client(), scene, kw, dpix, W, H, n, tmp_path, mode="records")
+    assert pi.tobytes() == ri.tobytes() and pd.tobytes() == rd.tobytes()
+    for k in pb:
+        assert pb[k].tobytes() == rb[k].tobytes(), k
+    parity.compare_backward(rg, pg)
+    assert float(np.abs(rg["dL_dmean2D"][:, 2]).max()) == 0.0 and float(np.abs(rg["dL_dconic"][:, 2]).max()) == 0.0
+    ref = oracle.render_gaussians(**kw)
+    parity.compare_forward((ri, rd, rb), ref)
+    parity.compare_backward(rg, oracle.backward(**backward_kwargs(scene, cam, kw, rb, dpix)))
