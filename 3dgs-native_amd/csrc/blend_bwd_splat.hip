@@ -13,7 +13,7 @@
 // instantiated) replays its tile's list back to front.  Most entries of a tile's list cannot touch a given block, so the wave first
 // COMPACTS the stream: 64 candidates at a time are tested against the block rectangle (exact convex
 // minimum of the conic over the rectangle vs ln(255 o), conservative) and survivors are queued in an
-// LDS ring in order; each full bucket of 64 survivors (lane 0 = deepest) then runs the pixel loop, so
+// LDS ring in order; each full bucket of survivors (32 since round 4, 64 before; lane 0 = deepest) then runs the pixel loop, so
 // lanes are mostly live.  Per-pixel carries (P, Q) live in LDS between buckets; pixels whose n_contrib
 // ends before the bucket are skipped wave-uniformly.
 // After a bucket each lane holds the block's complete gradient for its entry; an LDS transpose lets 16
