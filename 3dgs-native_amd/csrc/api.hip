@@ -268,6 +268,8 @@ int check_count(const void *ws, int64_t N, int64_t D)
     return -1;
 }
 
+bool fwd_order_wanted(int tiles) { return tiles > 0 && tiles <= GSR_FO_MAX_TILES && !gsr_fwd_no_order && !gsr_fwd_xcd_map; }
+
 std::once_flag g_tuning_once;
 void read_tuning()
 {
@@ -277,6 +279,7 @@ void read_tuning()
         if (const char *e = getenv("GSR_BWD_XCD")) gsr_bwd_xcd_map = atoi(e);
         if (const char *e = getenv("GSR_FWD_XCD")) gsr_fwd_xcd_map = atoi(e) != 0;
         if (const char *e = getenv("GSR_BWD_NO_ORDER")) gsr_bwd_no_order = atoi(e) != 0;
+        if (const char *e = getenv("GSR_FWD_NO_ORDER")) gsr_fwd_no_order = atoi(e) != 0;
     });
 }
 
@@ -286,7 +289,7 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
 {
     Carver c(base);
     GeomWs w;
-    w.rec = c.take<BlendRec>((size_t)N);
+    w.rec = c.take<BlendRec>((size_t)N); // FIRST: a caller may hand the start of geom_ws back to gsr_backward as GsrGeom.blend_records
     w.rect = c.take<TileRect>((size_t)N);
     w.depth_item = c.take<uint64_t>((size_t)N);
     w.sort_tmp = c.take<uint64_t>((size_t)N);
@@ -302,6 +305,8 @@ GeomWs gsr_carve_geom(void *base, int64_t N)
     w.acc[1] = w.acc[0] ? w.acc[0] + gsr_radix_acc_ints(N) : nullptr;
     w.acc_first = w.acc[0] ? w.acc[0] + 2 * gsr_radix_acc_ints(N) : nullptr;
     w.sum4096 = c.take<int32_t>((size_t)gsr_div_up(N, 4096) + 4);
+    w.fwd_cost = c.take<int32_t>(4 * (size_t)GSR_FO_MAX_TILES); // (behind everything else: they move when N changes, and the order
+    w.fwd_order = c.take<int32_t>((size_t)GSR_FO_MAX_TILES);    // made from a moved -- i.e. arbitrary -- cost table is still a permutation)
     w.bytes = c.off + 256;
     return w;
 }
@@ -363,7 +368,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     const GeomWs ws = gsr_carve_geom(geom_ws, N);
     const int st = t_fwd_record = timer_open(true);
     mark(st, 0, s);
-    HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s));
+    HIP_TRY(gsr_launch_preprocess(*scene, cam, *geom, ws, s, fwd_order_wanted(cam.grid_x * cam.grid_y)));
     mark(st, 1, s);
     ReadbackLease lease;
     Readback *rb = lease.r;
@@ -464,6 +469,9 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     int32_t *order = binning->block_masks ? binning->block_order : nullptr;
     const bool file_order = order && tiles <= GSR_BO_MAX_TILES;
     const bool by_gaussian = (gsr_debug_flags & 512) != 0; // GSR_DEBUG bit 9: the expansion by Gaussian + the first pass's own histogram kernel (tests, A/B)
+    // the forward blend's tiles by last frame's cost classes (gsr_internal.h "forward tile order"): the table was made by the spare
+    // workgroup of this frame's preprocess (gsr_forward_count, same condition), so it is never stale or foreign
+    const bool use_fwd_order = fwd_order_wanted(tiles);
     if (by_gaussian) {
         mark(st, 5, s);
         HIP_TRY(gsr_launch_expand(gw.id_sorted, gw.doff, gw.rect_sorted, bw.tile_a, N, cam.grid_x, D, id_shift, item_bytes, binning->ranges, 2 * tiles, bw.acc[0],
@@ -506,7 +514,7 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
         clear_bytes = sizeof(GradRec) * (size_t)N;
     }
     HIP_TRY(gsr_launch_blend_forward(cam, binning->ranges, binning->point_list, geom->blend_records ? (const BlendRec *)geom->blend_records : gw.rec, *image, binning->block_masks, file_order ? order : nullptr,
-                                     clear, clear_bytes, s));
+                                     clear, clear_bytes, s, use_fwd_order ? gw.fwd_order : nullptr, tiles <= GSR_FO_MAX_TILES ? gw.fwd_cost : nullptr));
     mark(st, 9, s);
     return GSR_OK;
 }

@@ -45,6 +45,7 @@ __device__ unsigned long long g_fwd_wave[TL_MAX_WAVES][8]; // one row per wave, 
 // GSR_CENSUS (diagnostic build, `make census`): the product kernel plus three scalar stamps per wave (HW_ID | XCC_ID,
 // s_memrealtime start / end) for tools/residency.py
 __device__ unsigned long long g_fwd_census[1 << 17][4];
+__device__ const int *g_fwd_order = nullptr; // experiment (tools/residency.py --fwd-order): launch slot -> tile
 #define TL_DECL const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
 #define TL(k)
 #define TL_COUNT(k, v)
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
                                                             float *__restrict__ inv_depth, float *__restrict__ final_T,
                                                             int32_t *__restrict__ n_contrib, uint8_t *__restrict__ block_masks, int xcd_map,
                                                             int n_tiles, int32_t *__restrict__ block_order, int bo_cap,
-                                                            float4 *__restrict__ clear4, long long clear_n4, int clear_wgs)
+                                                            float4 *__restrict__ clear4, long long clear_n4, int clear_wgs,
+                                                            const int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_cost)
 {
     // Spare workgroups behind the tiles' (clear_wgs of them, when the caller handed over its backward workspace): they clear the
     // backward's accumulator records.  They are dispatched after every tile's workgroup, i.e. as the kernel starts to drain and
@@ -176,7 +178,12 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     if (xcd_map) {
         tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
         if (tile >= n_tiles) return;
+    } else if (tile_order) {
+        tile = tile_order[blockIdx.x]; // heaviest class first, by what the tiles cost a frame ago (gsr_internal.h "forward tile order")
     }
+#ifdef GSR_CENSUS
+    if (g_fwd_order) tile = g_fwd_order[blockIdx.x];
+#endif
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int pix_x = tile_x * 16 + (wv & 1) * 8 + (lane & 7);
     const int pix_y = tile_y * 16 + (wv >> 1) * 8 + (lane >> 3);
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     // the batch that was prefetched with it, then goes: the others' next wait for it falls under their walk of that batch.
     __shared__ int s_alive;
     if (tid == 0) s_alive = 0xF;
-    int alive_cur = 0xF;
+    int alive_cur = 0xF, walked = 0; // walked: list entries this wave blended (its share of the tile's cost, for the next frame's order)
     const int wv_u = __builtin_amdgcn_readfirstlane(wv); // wave-uniform copy: the bookkeeping below stays in scalar registers
     auto rank_in = [&](int set) { return __popc(set & ((1 << wv_u) - 1)); };
     int nid = (start + tid < end) ? point_list[start + tid] : -1;
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         na = rp[0]; nb = rp[1];
         ncd = *reinterpret_cast<const float2 *>(rp + 2);
     }
+    int staged = 0; // list entries staged by the time this wave leaves
     for (int base = start; base < end;) {
         __syncthreads(); // every surviving wave has walked the last batch (LDS reuse) and the leavers' bits are cleared
         TL(0)
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         TL(4) // list build
         TL_COUNT(7, (unsigned long long)n)
+        walked += n;
 
         // walk the list; two-deep software pipeline: the offset of entry k+2 and the record of entry k+1 are in flight while
         // entry k is blended
@@ -345,6 +354,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         done = pixf_x == PARKED_X;
         TL(5)
         base += cnt;
+        staged = base - start;
         alive_cur = alive_next;
         if (__all(done) && base < end) {
             if (lane == 0) atomicAnd(&s_alive, ~(1 << wv_u)); // the next top barrier is behind this
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         image[3 * px + 2] = cb + T * bg2;
         inv_depth[px] = cd;
     }
+    if (tile_cost && lane == 0) tile_cost[tile * 4 + wv] = (min(walked, 0x7FFF) << 16) | min(staged, 0xFFFF);
     if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, tile, start, last);
     TL(6)
     TL_FLUSH
@@ -367,6 +378,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
 } // namespace
 
 #ifdef GSR_CENSUS
+extern "C" int gsr_debug_fwd_order(const int *order_dev) // device array [tiles] or NULL
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_order), &order_dev, sizeof(order_dev)) == hipSuccess ? 0 : -1;
+}
 extern "C" int gsr_debug_fwd_census(unsigned long long *out /* [waves][4] */, int waves, int clear)
 {
     if (waves > (1 << 17)) return -1;
@@ -387,10 +402,11 @@ extern "C" int gsr_debug_fwd_phases(unsigned long long *out /* [waves][8] */, in
 #endif
 
 int gsr_fwd_xcd_map = 0; // GSR_FWD_XCD (see the kernel)
+int gsr_fwd_no_order = 0; // GSR_FWD_NO_ORDER: row-major dispatch instead of last frame's cost classes
 
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
                                     const GsrImage &img, uint8_t *block_masks, int32_t *block_order, void *clear, size_t clear_bytes,
-                                    hipStream_t s)
+                                    hipStream_t s, const int32_t *tile_order, int32_t *tile_cost)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
@@ -404,6 +420,7 @@ hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, cons
     const int grid = (gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles) + clear_wgs;
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
                        ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks, gsr_fwd_xcd_map, tiles,
-                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles), reinterpret_cast<float4 *>(clear), clear_n4, clear_wgs);
+                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles), reinterpret_cast<float4 *>(clear), clear_n4, clear_wgs,
+                       gsr_fwd_xcd_map ? nullptr : tile_order, tile_cost);
     return hipGetLastError();
 }

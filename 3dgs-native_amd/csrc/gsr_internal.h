@@ -33,6 +33,8 @@ static inline bool gsr_aligned16(const void *p) { return ((uintptr_t)p & 15u) ==
 static inline int64_t gsr_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+#define GSR_FO_MAX_TILES 4096  // forward tile order (see below): images of at most this many tiles
+#define GSR_FO_CLASSES 64
 // ---- layout of the geom workspace (persists from gsr_forward_count to gsr_forward_render) ----
 struct GeomWs {
     BlendRec *rec;        // [N]
@@ -50,12 +52,15 @@ struct GeomWs {
     int32_t *acc[2];      // [gsr_radix_acc_ints(N)] each: digit + super-block totals of a pass; consecutive passes alternate
     int32_t *acc_first;   // [gsr_radix_acc_ints(N)] behind acc[1]: the first ACTIVE depth pass's accumulators (filled beside the id-order scan)
     int32_t *sum4096;     // [N / 4096 + 1] tile pairs per 4096 depth-sorted Gaussians (depth_block_offsets_kernel; scan_tmp holds the 256-level)
+    int32_t *fwd_cost;    // [4 * GSR_FO_MAX_TILES] what the forward blend's waves walked / staged LAST frame ("forward tile order" below);
+    int32_t *fwd_order;   // [GSR_FO_MAX_TILES]     this frame's dispatch order made from it (last in the workspace)
     size_t bytes;
 };
 GeomWs gsr_carve_geom(void *base, int64_t N);
 
 // ---- launchers (host functions; each enqueues on `s` and returns hipGetLastError()) ----
-hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s);
+hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s,
+                                 bool make_fwd_order = false /* a spare workgroup turns ws.fwd_cost into ws.fwd_order */);
 
 // Device-wide scan of int32.  mode 0: out[i] = inclusive scan of in[i].
 // mode 2: out[i] = exclusive scan of in[i] (total_out still receives the grand total).
@@ -129,6 +134,18 @@ hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, con
 // The product path of the expansion (scan_sort.hip): one prefix per 256 depth-sorted Gaussians (into ws.scan_tmp; also clears the
 // ranges, the first partition pass's accumulators and the block-order header), then one workgroup per radix block of the output,
 // which also leaves the first partition pass's histograms (launch that pass with hist_ready).
+// ---- forward tile order (round 4) ----
+// The forward blend's 2 500 workgroups at 800 x 800 run on 2 048 workgroup slots: the 452 that start when the first slots free up
+// decide when the kernel ends (they start at 0.4 of its span and live half of it).  An oracle experiment (tools/residency.py
+// --fwd-order: dispatch the tiles heaviest first by their MEASURED lives) takes the kernel from 113 to 94 us; by list length, which
+// is known before the blend, from 113 to 108 (rank correlation 0.05-0.16 with the life: saturation cuts every deep list at about the
+// same depth).  What does predict a tile's work is the tile's work a frame ago: a trainer comes back to its views, a viewer moves
+// its camera smoothly.  So every wave of the forward blend leaves behind what it walked and staged (fwd_cost, 4 ints per tile, in
+// the caller's geom workspace, which persists between frames as long as the caller keeps it), and the next forward on that
+// workspace dispatches the tiles by cost class, heaviest first (fwd_order, made by a spare workgroup of preprocess_kernel
+// every frame from whatever fwd_cost holds -- garbage in a fresh workspace gives some permutation, never a wrong one).  Execution
+// order only: every tile computes what it always did.  Not for images of more than GSR_FO_MAX_TILES tiles (many rounds, no tail).
+extern int gsr_fwd_no_order; // GSR_FWD_NO_ORDER: plain row-major dispatch (A/B)
 hipError_t gsr_launch_depth_block_offsets(const GeomWs &ws, int64_t n, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n, int32_t *zero_b,
                                           int zero_b_n, int bo_flag, hipStream_t s);
 hipError_t gsr_launch_expand_blocks(const GeomWs &ws, void *tile_items, int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int bits0,
@@ -172,7 +189,8 @@ __host__ __device__ static inline int gsr_bo_class(int hits)
 hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                     const BlendRec *rec, const GsrImage &img, uint8_t *block_masks /* optional out */,
                                     int32_t *block_order /* optional out, with block_masks */,
-                                    void *clear, size_t clear_bytes /* optional: memory its spare workgroups zero (16-byte units) */, hipStream_t s);
+                                    void *clear, size_t clear_bytes /* optional: memory its spare workgroups zero (16-byte units) */, hipStream_t s,
+                                    const int32_t *tile_order = nullptr /* optional: launch slot -> tile */, int32_t *tile_cost = nullptr /* optional out: 4 per tile */);
 
 // backward
 struct __attribute__((aligned(16))) GradRec { // 64 B accumulator per Gaussian (atomics target)

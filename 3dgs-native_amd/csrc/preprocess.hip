@@ -12,6 +12,7 @@
 // Gaussians, quirk Q11), so no buffer needs pre-zeroing.
 #include "gsr_internal.h"
 #include "sh_stage.h"
+#include "fwd_order.h"
 
 namespace {
 
@@ -65,14 +66,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ tiles_touched,
     float *__restrict__ clamped_state, BlendRec *__restrict__ rec, TileRect *__restrict__ rect,
     uint64_t *__restrict__ depth_item, int32_t *__restrict__ zero_acc, int zero_n, int32_t *__restrict__ block_tile_sums,
-    float *__restrict__ sh_dir_grad, uint32_t *__restrict__ blk_minmax, int dbg)
+    float *__restrict__ sh_dir_grad, uint32_t *__restrict__ blk_minmax, int dbg, const int32_t *__restrict__ fwd_cost,
+    int32_t *__restrict__ fwd_order, int n_tiles)
 {
+    const unsigned nblk = gridDim.x - (fwd_order ? 1u : 0u); // the workgroups that hold Gaussians
     __shared__ int s_tiles[4];
     __shared__ uint32_t s_dmin[4], s_dmax[4], s_dvis[4];
-    // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
-    for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * 256) zero_acc[z] = 0;
     // SH rows are fetched wave-cooperatively (coalesced) into LDS while the geometry math runs
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
+    // the spare workgroup behind the Gaussians' (launched when the forward blend wants a tile order): see fwd_order.h
+    if (fwd_order && blockIdx.x == nblk) {
+        fwd_order_block(fwd_cost, fwd_order, n_tiles, reinterpret_cast<int *>(s_rows));
+        return;
+    }
+    // the accumulators of the first depth-sort pass (scan_sort.hip, radix_hist_kernel) are cleared here: saves a memset launch
+    for (int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (int64_t)nblk * 256) zero_acc[z] = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave_row0 = (int64_t)blockIdx.x * blockDim.x + wv * 64;
     float4 *lds_wave = s_rows + wv * SH_WAVE_F4;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                                                                        max(max(s_dmax[0], s_dmax[1]), max(s_dmax[2], s_dmax[3])),
                                                                        s_dvis[0] + s_dvis[1] + s_dvis[2] + s_dvis[3], 0u);
         // the slot behind the last block is the frame's DepthCtlRaw (scan_sort.hip): cleared here, combined into by the scan's launch
-        if (blockIdx.x == 0) reinterpret_cast<uint4 *>(blk_minmax)[gridDim.x] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0) reinterpret_cast<uint4 *>(blk_minmax)[nblk] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (need_sh) {
                 // SH colour (forward.py:304-372), stride 16 coefficients per Gaussian
@@ -300,16 +308,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 
 } // namespace
 
-hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s)
+hipError_t gsr_launch_preprocess(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GeomWs &ws, hipStream_t s, bool make_fwd_order)
 {
     if (sc.N == 0) return hipSuccess;
     const int threads = 256;
-    const unsigned blocks = (unsigned)gsr_div_up(sc.N, threads);
+    const unsigned blocks = (unsigned)gsr_div_up(sc.N, threads) + (make_fwd_order ? 1u : 0u);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(threads), 0, s, sc.N, sc.means, sc.scales, sc.rotations,
                        sc.opacity, sc.sh, sc.sh_degree, sc.clamped, sc.scale_modifier, cam, g.radii, g.xy, g.depths,
                        g.cov3D, g.rgb, g.conic_opacity, g.tiles_touched, g.clamped_state,
                        g.blend_records ? (BlendRec *)g.blend_records : ws.rec /* the caller's record buffer, else the workspace's */, ws.rect, ws.depth_item, ws.acc[0],
                        3 * (int)gsr_radix_acc_ints(sc.N) /* acc[0], acc[1] (the depth sort may start at a later pass) and acc_first */, ws.scan_tmp, g.sh_dir_grad,
-                       ws.blk_minmax, gsr_debug_flags);
+                       ws.blk_minmax, gsr_debug_flags, ws.fwd_cost, make_fwd_order ? ws.fwd_order : nullptr, cam.grid_x * cam.grid_y);
     return hipGetLastError();
 }

@@ -27,6 +27,17 @@ def test_parity_with_forced_paths(flags):
     assert " passed" in r.stdout
 
 
+def test_parity_with_the_plain_tile_dispatch():
+    """GSR_FWD_NO_ORDER=1: the forward blend dispatches its tiles row-major instead of by last frame's cost classes (the product's
+    default since round 4).  Same outputs either way; the parity and fuzz suites run once more with the plain order."""
+    env = dict(os.environ, GSR_FWD_NO_ORDER="1", GSR_FUZZ_CASES="48", GSR_NEEDLE_CASES="4")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"), os.path.join(ROOT, "tests", "test_gpu_properties.py"),
+                        "-k", "not png and not full_size"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_two_training_steps_with_the_forward_xcd_map():
     """GSR_FWD_XCD=1 (neighbouring tiles of the forward blend on one XCD) cannot host the spare workgroups that clear the backward's
     accumulators; the forward must then clear them another way, or the SECOND step's gradients would carry the first step's sums

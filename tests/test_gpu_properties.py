@@ -119,3 +119,24 @@ def test_views_in_flight_on_separate_streams(cameras, scenes):
             assert torch.equal(b0[k], b1[k]), k
         m = float(g0["dL_dmean3D"].abs().max())
         assert float((g0["dL_dmean3D"] - g1["dL_dmean3D"]).abs().max()) <= 1e-4 * m      # float-atomic order only
+
+
+def test_forward_tile_order_changes_only_the_dispatch(cameras, scenes):
+    """Round 4: the forward blend dispatches its tiles heaviest first by what they cost LAST frame (costs kept in the geom workspace,
+    the order made by a spare workgroup of this frame's preprocess).  Whatever the table holds -- a fresh workspace's garbage on the
+    first call, another camera's costs, another image size's -- the outputs must be those of the plain row-major dispatch, bit for
+    bit: the same scene is rendered from three cameras in turn, twice round, and at a second image size in between."""
+    import torch
+    gsr = pkg()
+    sc = scenes.synthetic_scene(40000, 0.03, 0.6, seed=71)
+    dev_sc = {k: torch.as_tensor(np.ascontiguousarray(v, np.float32)).cuda() for k, v in sc.items()}
+    seen = {}
+    for rnd in range(3):
+        for f, (w, h) in ((0, (320, 240)), (3, (320, 240)), (5, (208, 176)), (6, (320, 240))):
+            cam = lego_camera(cameras, frame=f, width=w, height=h)
+            img, depth, buf = gsr.render_gaussians(**render_kwargs(dev_sc, cam, width=w, height=h))
+            got = (img.clone(), buf["final_Ts"].clone(), buf["n_contrib"].clone(), buf["point_list"].clone(), buf["ranges"].clone())
+            if (f, w) in seen:
+                for a, b in zip(seen[(f, w)], got):
+                    assert torch.equal(a, b), (rnd, f)
+            seen[(f, w)] = got

@@ -199,3 +199,63 @@ if "--lpt" in sys.argv:
             band = np.arange(x * per, (x + 1) * per)
             tab[x::8] = band[np.argsort(cls[band], kind="stable")]
         timed(tab, f"8 classes by [{nm}] (rank corr. with life {rho:.2f})")
+
+
+# ---- experiment: what would a tile order for the FORWARD blend buy?  (--fwd-order)
+# Oracle: the measured tile lives of the run above (max over the tile's four waves).  Orders that keep row-major order INSIDE each
+# class (neighbouring tiles share their records in L2: a fully sorted order cost +23 us in round 3): the K lightest tiles last
+# (K = tiles beyond the 2048 workgroup slots: they become the second round), the heaviest quarter first, both.
+if "--fwd-order" in sys.argv:
+    arr = np.zeros((nw["fwd"], 4), np.uint64)
+    assert fn["fwd"](arr.ctypes.data_as(C.c_void_p), nw["fwd"], 0) == 0
+    life = (arr[:, 2].astype(np.int64) - arr[:, 1].astype(np.int64)).astype(np.float64).reshape(tiles, 4).max(axis=1)
+    slots = 2048
+
+    def timed_fwd(order, label):
+        od = torch.as_tensor(order.astype(np.int32)).cuda() if order is not None else None
+        assert L.gsr_debug_fwd_order(C.c_void_p(od.data_ptr() if od is not None else 0)) == 0
+        spans = []
+        for _ in range(5):
+            assert fn["fwd"](None, nw["fwd"], 1) == 0
+            step()
+            torch.cuda.synchronize()
+            a = np.zeros((nw["fwd"], 4), np.uint64)
+            assert fn["fwd"](a.ctypes.data_as(C.c_void_p), nw["fwd"], 0) == 0
+            ok = a[:, 1] > 0
+            spans.append((a[ok, 2].max() - a[ok, 1].min()) / 100.0)
+        print(f"   {label:72s} span us: " + " ".join(f"{x:.1f}" for x in spans))
+
+    ids = np.arange(tiles)
+    K = max(0, tiles - slots)
+    rank = np.argsort(np.argsort(life))              # 0 = lightest
+    light = rank < K
+    heavy = rank >= tiles - tiles // 4
+    print(f"== forward tile order experiment ({name}): {tiles} tiles, {slots} slots, K = {K}; tile life us p10 {np.percentile(life, 10) / 100:.1f} p50 {np.percentile(life, 50) / 100:.1f} p90 {np.percentile(life, 90) / 100:.1f}")
+    timed_fwd(None, "row-major (the product)")
+    timed_fwd(ids, "row-major through the table (the table's own cost)")
+    timed_fwd(np.concatenate([ids[~light], ids[light]]), "the K lightest tiles last, row-major inside both classes")
+    timed_fwd(np.concatenate([ids[heavy], ids[~heavy & ~light], ids[light]]), "heaviest quarter first, lightest K last, row-major inside the classes")
+    timed_fwd(np.argsort(-life, kind="stable"), "fully sorted, heaviest first (no locality)")
+    # a predictor that needs no previous frame: the tile's list length
+    lrank = np.argsort(np.argsort(list_len))
+    timed_fwd(np.concatenate([ids[lrank >= K], ids[lrank < K]]), "the K tiles with the SHORTEST LISTS last (no oracle)")
+    # is it the prediction at all, or just that ANY order which is not row-major spreads neighbouring (similar) tiles over the CUs?
+    rng = np.random.default_rng(3)
+    timed_fwd(rng.permutation(tiles), "a random permutation (no cost information at all)")
+    for stride in (389, 577, 1009):
+        timed_fwd((ids * stride) % tiles if np.gcd(stride, tiles) == 1 else ids, f"stride permutation, tile = slot * {stride} mod tiles")
+    gx = (W + 15) // 16
+    gy = tiles // gx
+    timed_fwd(np.concatenate([np.arange(r, gy, 8) for r in range(8)])[:, None].repeat(gx, 1).__mul__(gx).__add__(np.arange(gx)[None, :]).reshape(-1), "tile rows interleaved by 8 (row r, r + 8, ...)")
+    # what the product's own predictor sees: the costs the waves left in the binning workspace (4 ints per tile: walked << 16 | staged)
+    host = importlib.import_module("3dgs-native_amd._host")
+    ws = [t for (kind, _, _), t in host._ws.items() if kind == "bin"][0]
+    raw = ws[:16 * tiles].view(torch.int32).cpu().numpy().reshape(tiles, 4)
+    walked, staged = (raw >> 16) & 0x7FFF, raw & 0xFFFF
+    cands = {"max walked": walked.max(1), "max staged": staged.max(1), "max (walked + staged / 8)": (walked + staged // 8).max(1),
+             "sum walked": walked.sum(1), "max walked + staged / 2": walked.max(1) + staged.max(1) // 2, "max walked + 2 staged": walked.max(1) + 2 * staged.max(1)}
+    for label, c in cands.items():
+        r = np.corrcoef(np.argsort(np.argsort(c)), np.argsort(np.argsort(life)))[0, 1]
+        cls = 63 - (c.astype(np.int64) * 63 // max(1, int(c.max())))
+        timed_fwd(np.argsort(cls, kind="stable"), f"64 classes of {label} (rank correlation with the life {r:.2f})")
+    assert L.gsr_debug_fwd_order(C.c_void_p(0)) == 0
