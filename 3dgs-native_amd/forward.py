@@ -20,7 +20,8 @@ from .config import TILE_M, TILE_N
 PRECLEAR_BACKWARD = not bool(int(os.environ.get("GSR_NO_PRECLEAR", "0")))
 _backward_seen = False          # set by backward.backward()
 _NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))
-_NO_RECORD_VIEWS = bool(int(os.environ.get("GSR_NO_RECORD_VIEWS", "0")))   # A/B switch: packed xy / conic_opacity / colors arrays beside the records   # A/B switch: backward reads the SH rows itself (same results)
+_NO_RECORD_VIEWS = bool(int(os.environ.get("GSR_NO_RECORD_VIEWS", "0")))
+_NO_BLOCK_ORDER = bool(int(os.environ.get("GSR_NO_BLOCK_ORDER", "0")))     # A/B switch: the forward does not file the backward's blocks by cost   # A/B switch: packed xy / conic_opacity / colors arrays beside the records   # A/B switch: backward reads the SH rows itself (same results)
 
 
 def render_gaussians(background, means3D, colors=None, opacity=None, scales=None, rotations=None, scale_modifier=1.0,
@@ -84,7 +85,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
         # backward reads them 16 at a time)
         block_masks = e((D + 16,), torch.uint8)[:D]
         # the backward blend's blocks filed by cost, heaviest first (GsrBinning.block_order): filled by the forward blend from the masks
-        block_order = e((int(L.gsr_block_order_ints(W, H)),), i32)
+        block_order = None if _NO_BLOCK_ORDER else e((int(L.gsr_block_order_ints(W, H)),), i32)
         # The backward's workspace, one per call: its accumulator records are what backward() returns dL_dcolor / dL_dmean2D /
         # dL_dconic as views of, so it must not be shared between calls.  Handed to the forward, its records are cleared by the
         # blend kernel's spare workgroups.

@@ -195,7 +195,13 @@ size_t gsr_block_order_ints(int32_t W, int32_t H); /* int32 elements of GsrBinni
  * (reference forward.py:719-767), plus the part of the sort that does not depend on D (Gaussians by
  * depth).  Fills *geom, leaves per-Gaussian blend records, depth-sorted ids and offsets in geom_ws
  * (which must be passed unchanged to gsr_forward_render), and returns D in *num_rendered (host
- * pointer).  GSR_E_OVERFLOW if D > GSR_MAX_RENDERED. */
+ * pointer).  GSR_E_OVERFLOW if D > GSR_MAX_RENDERED.
+ *
+ * A hint, not a requirement: a caller that keeps ONE geom_ws per stream from frame to frame (instead of a fresh one per call) gets
+ * a faster forward blend.  The last 80 KB of the workspace hold what every tile of the previous frame cost, and this call turns that
+ * into the order in which gsr_forward_render's blend dispatches its tiles (heaviest first; images of up to 4 096 tiles).  Whatever
+ * those bytes hold -- a fresh allocation's garbage, another camera's or another image size's costs -- the order is a permutation of
+ * the tiles and every output is the same, bit for bit; only the blend's duration changes (-9 % at 800 x 800 with 1 M Gaussians). */
 int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom,
                       void *geom_ws, size_t geom_ws_bytes, int64_t *num_rendered, void *stream);
 
