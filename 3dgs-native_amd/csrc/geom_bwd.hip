@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
             const int j = k * 64 + lane;
             dg4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row_mask != 0ull && j < 144) {
-                if (4 * j + 3 < nfl) dg4[k] = reinterpret_cast<const float4 *>(g)[j];
+                if (4 * j + 3 < nfl) dg4[k] = gsr_ld4<GSR_NT_INPUTS != 0>(reinterpret_cast<const float4 *>(g) + j);
                 else {
                     if (4 * j < nfl) dg4[k].x = g[4 * j];
                     if (4 * j + 1 < nfl) dg4[k].y = g[4 * j + 1];
@@ -119,11 +119,11 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     // API-layout copies of the blend-stage gradients, for a caller that wants packed arrays (NULL: it reads the record's columns)
     // (dL_dcolor and dL_dmean2D: 12-byte rows, written wave-cooperatively at the end of the kernel)
     if (dL_dconic) *reinterpret_cast<float4 *>(dL_dconic + 4 * idx) = make_float4(g_con[0], g_con[1], 0.0f, g_con[2]);
-    dL_dopacity[idx] = a8;
+    gsr_st1<GSR_NT_MISC_STORE != 0>(dL_dopacity + idx, a8);
 
     vis = my_radius > 0;
     if (vis) {
-        mean[0] = means[3 * idx]; mean[1] = means[3 * idx + 1]; mean[2] = means[3 * idx + 2];
+        mean[0] = gsr_ld1<GSR_NT_INPUTS != 0>(means + 3 * idx); mean[1] = gsr_ld1<GSR_NT_INPUTS != 0>(means + 3 * idx + 1); mean[2] = gsr_ld1<GSR_NT_INPUTS != 0>(means + 3 * idx + 2);
         // ---------------- cov2d backward (backward.py:259-435) ----------------
         {
             float c3[6];
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
         // ---------------- cov3d backward (backward.py:439-556), scale_modifier = 1.0 (Q16) ----------------
         {
             const float scale_modifier = 1.0f;
-            const float sv[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
-            const float4 q = *reinterpret_cast<const float4 *>(rots + 4 * idx);
+            const float sv[3] = {gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx), gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx + 1), gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx + 2)};
+            const float4 q = gsr_ld4<GSR_NT_INPUTS != 0>(reinterpret_cast<const float4 *>(rots + 4 * idx));
             const float r = q.w, x = q.x, y = q.y, z = q.z;
             const M33 R = {{{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
                             {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
         }
     }
 
-    *reinterpret_cast<float4 *>(dL_drot + 4 * idx) = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+    gsr_st4<GSR_NT_MISC_STORE != 0>(reinterpret_cast<float4 *>(dL_drot + 4 * idx), make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]));
     if (dL_drgb) {
         if (idx == 0) { // the payload's trailer: where this view was taken from
             dL_drgb[3 * N] = cam.campos[0]; dL_drgb[3 * N + 1] = cam.campos[1]; dL_drgb[3 * N + 2] = cam.campos[2]; dL_drgb[3 * N + 3] = 0.0f;

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     TileRect o_rect = {0, 0, 0, 0};
     bool visible = false, need_sh = false;
 
-    const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+    constexpr bool NTI = GSR_NT_INPUTS != 0, NTM = GSR_NT_MISC_STORE != 0;
+    const float px = gsr_ld1<NTI>(means + 3 * i), py = gsr_ld1<NTI>(means + 3 * i + 1), pz = gsr_ld1<NTI>(means + 3 * i + 2);
     float p_view[4], p_hom[4];
     rowvec_mul44(px, py, pz, cam.view, p_view);
     rowvec_mul44(px, py, pz, cam.proj, p_hom);
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         // down, where its load was a third memory round trip behind the first two (the kernel ran 44 us with neither the SH
         // fetch nor any store, i.e. on latency): 87 -> 82 us at C3, 312 -> 304 us at C5.  Hoisting all three above the near-plane
         // test as well measured the same, and would read 32 B for every Gaussian behind the camera.
-        float sc_x = scales[3 * i], sc_y = scales[3 * i + 1], sc_z = scales[3 * i + 2];
-        float4 q = *reinterpret_cast<const float4 *>(rots + 4 * i);
-        float opacity_i = opac[i];
+        float sc_x = gsr_ld1<NTI>(scales + 3 * i), sc_y = gsr_ld1<NTI>(scales + 3 * i + 1), sc_z = gsr_ld1<NTI>(scales + 3 * i + 2);
+        float4 q = gsr_ld4<NTI>(reinterpret_cast<const float4 *>(rots + 4 * i));
+        float opacity_i = gsr_ld1<NTI>(opac + i);
         asm volatile("" : "+v"(sc_x), "+v"(sc_y), "+v"(sc_z), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(opacity_i)); // not to be sunk back
         const float sx = scale_mod * sc_x, sy = scale_mod * sc_y, sz = scale_mod * sc_z;
         M33 R;
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
     if (!in_range) return;
     if (GSR_ABL(dbg, 8)) { if (o_rgb[0] + o_cov[0] + o_con[0] + o_xy[0] + o_depth == 123.456f) radii[i] = 1; } else {
-    radii[i] = o_radius;
+    gsr_st1i<NTM>(radii + i, o_radius);
     tiles_touched[i] = o_tiles;
     if (xy) *reinterpret_cast<float2 *>(xy + 2 * i) = make_float2(o_xy[0], o_xy[1]);
-    depths[i] = o_depth;
+    gsr_st1<NTM>(depths + i, o_depth);
     if (conic_opacity) *reinterpret_cast<float4 *>(conic_opacity + 4 * i) = make_float4(o_con[0], o_con[1], o_con[2], o_con[3]);
     }
 

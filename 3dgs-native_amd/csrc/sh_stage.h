@@ -8,6 +8,45 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Non-temporal loads and stores for the use-once streams of the two per-Gaussian kernels (compile-time switches, all ON in the
+// product; -DGSR_NT_...=0 for A/B: DESIGN "Round 4: streaming policy").  On this pool a float4 copy runs at 5.0-5.9 TB/s with the
+// default cache policy and 6.1-6.4 TB/s with nt loads and stores (tools/copy_bw.hip): a line that will not be read again should
+// not push one that will out of L2 / the Infinity Cache, and a kernel should pay for its own write-back instead of leaving 200 MB
+// of dirty lines to its successor.  Round 3 had tried two of these streams alone and found a zero-sum (preprocess faster, the
+// geometry backward slower); with ALL of them nt, preprocess goes 87.9 -> 73.5 us, the geometry backward 85.3 -> 76.2 and the step
+// 0.5756 -> 0.5462 ms (profiles/r04_h_ab_nontemporal_streams.txt).  What stays on the default policy is what a later kernel
+// re-reads soon: tile counts, rectangles and depth items (scan, sort), the sort's items, point_list, block masks, accumulators.
+typedef float gsr_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 gsr_ld4(const float4 *p)
+{
+    if (NT) { const gsr_f4 q = __builtin_nontemporal_load(reinterpret_cast<const gsr_f4 *>(p)); return make_float4(q.x, q.y, q.z, q.w); }
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void gsr_st4(float4 *p, const float4 v)
+{
+    if (NT) { const gsr_f4 q = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(q, reinterpret_cast<gsr_f4 *>(p)); }
+    else *p = v;
+}
+template <bool NT> __device__ __forceinline__ float gsr_ld1(const float *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ int gsr_ld1i(const int32_t *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void gsr_st1(float *p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool NT> __device__ __forceinline__ void gsr_st1i(int32_t *p, int32_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+#ifndef GSR_NT_INPUTS
+#define GSR_NT_INPUTS 1       // the per-Gaussian inputs of preprocess / geom_bwd read once per kernel (positions, scales, rotations, opacity, Sigma3D ...)
+#endif
+#ifndef GSR_NT_MISC_STORE
+#define GSR_NT_MISC_STORE 1   // per-lane outputs nobody reads soon (radii, depths; dL_drot, dL_dopacity)
+#endif
+#ifndef GSR_NT_SH_LOAD
+#define GSR_NT_SH_LOAD 1      // the 192-byte SH rows (preprocess; geom_bwd when it has no direction sums)
+#endif
+#ifndef GSR_NT_ROW_STORE
+#define GSR_NT_ROW_STORE 1    // preprocess' AoS outputs (Sigma3D, clamp flags, direction sums, blend records)
+#endif
+#ifndef GSR_NT_GRAD_STORE
+#define GSR_NT_GRAD_STORE 1   // geom_bwd's gradient rows (192-byte SH gradient rows, the 12-byte rows)
+#endif
+
 #define SH_ROW_F4 13                      // padded row length in float4
 #define SH_WAVE_F4 (64 * SH_ROW_F4)       // LDS float4 per wave
 
@@ -22,7 +61,7 @@ __device__ __forceinline__ void sh_rows_fetch(const float4 *__restrict__ g4, ShR
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         const int i = k * 64 + lane;
-        regs.v[k] = ((row_mask >> (i / 12)) & 1ull) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        regs.v[k] = ((row_mask >> (i / 12)) & 1ull) ? gsr_ld4<GSR_NT_SH_LOAD != 0>(g4 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 __device__ __forceinline__ unsigned long long sh_rows_all(int rows_valid) { return rows_valid >= 64 ? ~0ull : ((1ull << rows_valid) - 1ull); }
@@ -63,7 +102,7 @@ __device__ __forceinline__ void sh_rows_store(float4 *__restrict__ g4, const flo
     for (int k = 0; k < 12; ++k) {
         const int i = k * 64 + lane;
         const int r = i / 12, c = i - r * 12;
-        if (r < rows_valid) g4[i] = lds_wave[r * SH_ROW_F4 + c];
+        if (r < rows_valid) gsr_st4<GSR_NT_GRAD_STORE != 0>(g4 + i, lds_wave[r * SH_ROW_F4 + c]);
     }
 }
 
@@ -100,7 +139,7 @@ __device__ __forceinline__ void wave_store_rows(float *__restrict__ g, float *ld
     for (int j0 = 0; j0 < NF4; j0 += 64) {
         const int j = j0 + lane;
         if (j < NF4) {
-            if (4 * j + 3 < nfl) reinterpret_cast<float4 *>(g)[j] = reinterpret_cast<const float4 *>(lds)[j];
+            if (4 * j + 3 < nfl) gsr_st4<GSR_NT_ROW_STORE != 0>(reinterpret_cast<float4 *>(g) + j, reinterpret_cast<const float4 *>(lds)[j]);
             else
                 for (int e = 4 * j; e < nfl && e < 4 * j + 4; ++e) g[e] = lds[e];
         }
@@ -125,7 +164,7 @@ __device__ __forceinline__ void wave_store_vec3_in_pad(float *__restrict__ g, fl
             const int e = 4 * lane + c;
             o[c] = img[(e / 3) * (SH_ROW_F4 * 4) + 48 + (e % 3)];
         }
-        if (4 * lane + 3 < nfl) reinterpret_cast<float4 *>(g)[lane] = make_float4(o[0], o[1], o[2], o[3]);
+        if (4 * lane + 3 < nfl) gsr_st4<GSR_NT_GRAD_STORE != 0>(reinterpret_cast<float4 *>(g) + lane, make_float4(o[0], o[1], o[2], o[3]));
         else
             for (int c = 0; c < 4; ++c)
                 if (4 * lane + c < nfl) g[4 * lane + c] = o[c];
