@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256) void depth_loss_kernel(const float *__restrict
 }
 
 // ---- f3: reference optimizer.py:7-139 (adam_update) ----
+// The SH rows of parameter and both moments (3 x 192 bytes in, 3 x 192 out per Gaussian: all of the update's traffic that matters)
+// are use-once streams like preprocess' and geom_bwd's: non-temporal (sh_stage.h; GSR_NT_ADAM=0 for A/B).
+#ifndef GSR_NT_ADAM
+#define GSR_NT_ADAM 1
+#endif
 struct AdamK {
     float beta1, beta2, omb1, omb2, eps, bc1, bc2;
 };
@@ -195,13 +200,13 @@ __global__ __launch_bounds__(256) void adam_sh_kernel(int64_t n4, float4 *__rest
                                                       float4 *__restrict__ v, float lr, AdamK k)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 pp = p[i], mm = m[i], vv = v[i];
-        const float4 gg = g[i];
+        float4 pp = gsr_ld4<GSR_NT_ADAM != 0>(p + i), mm = gsr_ld4<GSR_NT_ADAM != 0>(m + i), vv = gsr_ld4<GSR_NT_ADAM != 0>(v + i);
+        const float4 gg = gsr_ld4<GSR_NT_ADAM != 0>(g + i);
         pp.x = adam_vec3_elem(pp.x, gg.x, mm.x, vv.x, lr, k);
         pp.y = adam_vec3_elem(pp.y, gg.y, mm.y, vv.y, lr, k);
         pp.z = adam_vec3_elem(pp.z, gg.z, mm.z, vv.z, lr, k);
         pp.w = adam_vec3_elem(pp.w, gg.w, mm.w, vv.w, lr, k);
-        p[i] = pp; m[i] = mm; v[i] = vv;
+        gsr_st4<GSR_NT_ADAM != 0>(p + i, pp); gsr_st4<GSR_NT_ADAM != 0>(m + i, mm); gsr_st4<GSR_NT_ADAM != 0>(v + i, vv);
     }
 }
 
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void adam_sh_views_kernel(int64_t N, const flo
         for (int q = 0; q < 4; ++q) {
             const int e = (q0 + q) * 64 + lane, r = e / 12;
             const int64_t g = wave_row0 * 12 + (r < rows_valid ? e : 0);
-            pp[q] = p[g]; mm[q] = m[g]; vv[q] = v[g];
+            pp[q] = gsr_ld4<GSR_NT_ADAM != 0>(p + g); mm[q] = gsr_ld4<GSR_NT_ADAM != 0>(m + g); vv[q] = gsr_ld4<GSR_NT_ADAM != 0>(v + g);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void adam_sh_views_kernel(int64_t N, const flo
                 a.z = adam_vec3_elem(a.z, gg.z, b.z, d.z, lr, k);
                 a.w = adam_vec3_elem(a.w, gg.w, b.w, d.w, lr, k);
                 const int64_t g = wave_row0 * 12 + e;
-                p[g] = a; m[g] = b; v[g] = d;
+                gsr_st4<GSR_NT_ADAM != 0>(p + g, a); gsr_st4<GSR_NT_ADAM != 0>(m + g, b); gsr_st4<GSR_NT_ADAM != 0>(v + g, d);
             }
         }
     }
