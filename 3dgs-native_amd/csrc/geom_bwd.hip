@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
             float c3[6];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float2 v = *reinterpret_cast<const float2 *>(cov3Ds + 6 * idx + 2 * k);
-                c3[2 * k] = v.x; c3[2 * k + 1] = v.y;
+                c3[2 * k] = gsr_ld1<GSR_NT_INPUTS != 0>(cov3Ds + 6 * idx + 2 * k); c3[2 * k + 1] = gsr_ld1<GSR_NT_INPUTS != 0>(cov3Ds + 6 * idx + 2 * k + 1);
             }
             float t[4];
 #pragma unroll
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
                 const float x = dir_orig[0] / dir_len, y = dir_orig[1] / dir_len, z = dir_orig[2] / dir_len;
                 float dRGB[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) dRGB[c] = g_col[c] * (1.0f + (-1.0f * clamped_state[3 * idx + c]));
+                for (int c = 0; c < 3; ++c) dRGB[c] = g_col[c] * (1.0f + (-1.0f * gsr_ld1<GSR_NT_INPUTS != 0>(clamped_state + 3 * idx + c)));
 #pragma unroll
                 for (int c = 0; c < 3; ++c) o_rgb[c] = dRGB[c];
                 // d(colour)/d(direction): nine sums over the coefficients (backward.py:120-244), either handed over by the forward
