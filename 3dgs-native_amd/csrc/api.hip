@@ -547,7 +547,7 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
     }
     mark(st, 11, s);
     if (D > 0) HIP_TRY(gsr_launch_blend_backward_splat(cam, binning->ranges, binning->point_list, records, *image, dL_dpixels, binning->block_masks,
-                                                       binning->block_masks ? binning->block_order : nullptr, bw.acc, s));
+                                                       binning->block_masks ? binning->block_order : nullptr, bw.acc, N, D, s));
     mark(st, 12, s);
     if (payload) HIP_TRY(gsr_launch_view_payload(*scene, cam, *geom, bw.acc, payload, s));
     return GSR_OK;

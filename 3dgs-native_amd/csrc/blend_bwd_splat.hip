@@ -594,14 +594,14 @@ extern "C" int gsr_debug_bwd_phases(unsigned long long *out /* [waves][12] */, i
 }
 #endif
 
-int gsr_bwd_block = 32;
+int gsr_bwd_block = 0;    // GSR_BWD_BLOCK: 0 = by the frame's tile pairs per Gaussian (see the launcher)
 int gsr_bwd_no_order = 0;  // GSR_BWD_NO_ORDER: ignore the forward's block order (A/B)
 int gsr_bwd_xcd_map = 1;   // GSR_BWD_XCD (see the kernel): on by default, 171 -> 165 us at C3
 int gsr_debug_flags = 0; // see gsr_internal.h
 
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list, const BlendRec *rec,
                                            const GsrImage &img, const float *dL_dpixels, const uint8_t *block_masks,
-                                           const int32_t *block_order, GradRec *acc, hipStream_t s)
+                                           const int32_t *block_order, GradRec *acc, int64_t N, int64_t D, hipStream_t s)
 {
     const int tiles = cam.grid_x * cam.grid_y;
     if (tiles <= 0) return hipSuccess;
@@ -616,7 +616,15 @@ hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *range
                            cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels,  \
                            block_masks, acc, gsr_debug_flags, gsr_bwd_xcd_map, nblk, bo, bo_cap);                             \
     } while (0)
-    switch (gsr_bwd_block) { // pixels per wave: GSR_BWD_BLOCK = 32 (8x4, default: measured best at C3), 64 (8x8), 16 (4x4)
+    // Pixels per wave.  The block masks discard an entry for a whole block, so small splats (few tile pairs per Gaussian) want the
+    // finer 8x4 blocks; splats that cover their tiles anyway want 8x8, which stages every entry in half as many waves.  Measured
+    // over D / N from 2.7 to 262 (tools/bwd_block_sweep.py, profiles/r04_q_bwd_block_size_sweep.txt): at 800 x 800 the curves
+    // cross at D / N of 18-22 (8x4 is 10-25 % faster below 13, 8x8 is 14-24 % faster above 40); images of more than
+    // GSR_BO_MAX_TILES tiles, whose 8x4 blocks the forward does not file by cost, cross at 4-5 already (1080p: 8x8 is 5-24 %
+    // faster from 5.4 up).  GSR_BWD_BLOCK = 32, 64 or 16 (4x4) forces one size.
+    const int64_t wide_from = tiles > GSR_BO_MAX_TILES ? GSR_BWD_WIDE_PAIRS_UNFILED : GSR_BWD_WIDE_PAIRS;
+    const int block_px = gsr_bwd_block > 0 ? gsr_bwd_block : (D >= wide_from * N ? 64 : 32);
+    switch (block_px) {
     case 16: LAUNCH(4, 4, false); break;
     case 64: if (block_masks) LAUNCH(8, 8, true); else LAUNCH(8, 8, false); break;
     default: if (block_masks) LAUNCH(8, 4, true); else LAUNCH(8, 4, false); break;

@@ -205,7 +205,8 @@ hipError_t gsr_launch_pack_records(const GsrGeom &g, BlendRec *rec, int64_t N, h
 hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *ranges, const int32_t *point_list,
                                            const BlendRec *rec, const GsrImage &img, const float *dL_dpixels,
                                            const uint8_t *block_masks /* optional: the forward's */,
-                                           const int32_t *block_order /* optional: the forward's, with its masks */, GradRec *acc, hipStream_t s);
+                                           const int32_t *block_order /* optional: the forward's, with its masks */, GradRec *acc,
+                                           int64_t N, int64_t D /* choose the block size */, hipStream_t s);
 hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const GsrGeom &g, const GradRec *acc,
                                     const GsrGrads &gr, hipStream_t s);
 
@@ -230,4 +231,6 @@ extern int gsr_debug_flags;
 extern int gsr_fwd_xcd_map;        // GSR_FWD_XCD: neighbouring tiles of the forward blend on one XCD (blend_fwd.hip)
 extern int gsr_bwd_no_order;
 extern int gsr_bwd_xcd_map;        // GSR_BWD_XCD: a tile's blocks of the backward blend on one XCD (blend_bwd_splat.hip)
-extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16)
+extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16); 0 = per frame
+#define GSR_BWD_WIDE_PAIRS 20         // D / N from which the backward blend takes 8x8 blocks instead of 8x4 ...
+#define GSR_BWD_WIDE_PAIRS_UNFILED 5  // ... and for images of more than GSR_BO_MAX_TILES tiles (no block order for 8x4 there)

@@ -38,6 +38,19 @@ def test_parity_with_the_plain_tile_dispatch():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("px", [16, 32, 64])
+def test_parity_with_each_backward_block_size(px):
+    """The backward blend picks 8x4 or 8x8 pixel blocks per frame from its tile pairs per Gaussian (D >= 24 N: 8x8); GSR_BWD_BLOCK
+    forces one size (4x4 too) for the whole process, so each kernel meets every parity and fuzz case, not only the frames that
+    would choose it."""
+    env = dict(os.environ, GSR_BWD_BLOCK=str(px), GSR_FUZZ_CASES="48", GSR_NEEDLE_CASES="4")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+                        "-k", "not png and not full_size"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_two_training_steps_with_the_forward_xcd_map():
     """GSR_FWD_XCD=1 (neighbouring tiles of the forward blend on one XCD) cannot host the spare workgroups that clear the backward's
     accumulators; the forward must then clear them another way, or the SECOND step's gradients would carry the first step's sums
