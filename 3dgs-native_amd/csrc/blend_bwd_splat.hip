@@ -257,8 +257,9 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
     const bool ordered = block_order && block_order[GSR_BO_FLAG] != 0; // the forward filed the blocks (it skips large images)
     if (ordered) {
     } else if (xcd_map == 1 || block_order) {
-        const int per = gridDim.x >> 3;
-        bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        const int per = (n_blocks + 7) >> 3, k = blockIdx.x >> 3; // (the grid of the ordered path may be larger than this needs)
+        if (k >= per) return;
+        bid = (blockIdx.x & 7) * per + k;
         if (bid >= n_blocks) return;
     } else if (xcd_map == 2) {
         const int k = blockIdx.x >> 3; // position in this XCD's queue
