@@ -220,6 +220,9 @@ constexpr int FILL_K = GSR_FILL_K;
 #ifndef GSR_BWD_SKIP2
 #define GSR_BWD_SKIP2 1     // 1: the two-pixel form skips a step when both pixels' replays have ended
 #endif
+#ifndef GSR_BWD_BUCKET_WIDE
+#define GSR_BWD_BUCKET_WIDE GSR_BWD_BUCKET   // the same for the 8x8 blocks (A/B)
+#endif
 constexpr int BUCKET = GSR_BWD_BUCKET;
 constexpr int QCAP = 128;                 // ring of compacted entries (power of two, >= 63 + 64): a chunk is consumed only while it fits
 
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(64) void blend_backward_splat_kernel(int W, int H, 
 
     int cursor = hi_all; // next list index (exclusive) to pull candidates from, moving towards `start`
     int head = 0, qn = 0; // ring state (wave-uniform)
-    constexpr int bucket = BUCKET; // entries per bucket (see GSR_BWD_BUCKET above)
+    constexpr int bucket = NPIX == 64 ? GSR_BWD_BUCKET_WIDE : BUCKET; // entries per bucket (see GSR_BWD_BUCKET above)
     TL(0) // prologue
     for (;;) {
         // ---- fill: pull candidates (deepest first) until a full bucket is queued or the list is exhausted ----
