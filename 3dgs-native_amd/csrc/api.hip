@@ -348,7 +348,7 @@ size_t gsr_block_order_ints(int32_t W, int32_t H)
     if (W <= 0 || H <= 0) return 0;
     const int64_t tiles = (int64_t)((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE);
     // images of more than GSR_BO_MAX_TILES tiles are never filed (gsr_internal.h): only the header (counters + the `filed` flag) is touched
-    return tiles > GSR_BO_MAX_TILES ? (size_t)GSR_BO_HEADER : gsr_bo_ints((int)tiles);
+    return tiles > GSR_BO_MAX_TILES ? (size_t)GSR_BO_HEADER : gsr_bo_ints((int)tiles, (W + GSR_TILE - 1) / GSR_TILE);
 }
 
 int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrGeom *geom, void *geom_ws, size_t geom_ws_bytes,

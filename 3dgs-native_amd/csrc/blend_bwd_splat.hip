@@ -614,8 +614,8 @@ hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *range
         const int nblk = tiles * (256 / ((BW) * (BH)));                                                                       \
         const int ppt = 256 / ((BW) * (BH)); /* map 2 walks whole groups of 8 tiles: grid = 8 * ppt * ceil(tiles / 8) */        \
         const int32_t *bo = ((M) && (BW) == 8 && (BH) == 4 && !gsr_bwd_no_order) ? block_order : nullptr; /* 8x4 blocks only */    \
-        const int bo_cap = gsr_bo_cap(tiles);                                                                                 \
-        const int grid = bo ? 8 * 8 * gsr_bo_tiles_per_band(tiles) : gsr_bwd_xcd_map == 2 ? 8 * ppt * ((tiles + 7) / 8) : gsr_bwd_xcd_map ? 8 * ((nblk + 7) / 8) : nblk; \
+        const int bo_cap = gsr_bo_cap(tiles, cam.grid_x);                                                                                 \
+        const int grid = bo ? 8 * 8 * gsr_bo_tiles_per_band(tiles, cam.grid_x) : gsr_bwd_xcd_map == 2 ? 8 * ppt * ((tiles + 7) / 8) : gsr_bwd_xcd_map ? 8 * ((nblk + 7) / 8) : nblk; \
         hipLaunchKernelGGL((blend_backward_splat_kernel<BW, BH, M>), dim3(grid), dim3(64), 0, s, cam.W, cam.H, cam.grid_x,    \
                            cam.bg[0], cam.bg[1], cam.bg[2], ranges, point_list, rec, img.final_T, img.n_contrib, dL_dpixels,  \
                            block_masks, acc, gsr_debug_flags, gsr_bwd_xcd_map, nblk, bo, bo_cap);                             \

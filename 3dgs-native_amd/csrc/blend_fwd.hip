@@ -115,7 +115,7 @@ struct StagedRec {
 // walk loop as well (70 VGPRs, 7 workgroups per CU instead of 8) and the kernel goes from 105 to 132 us; as a call made once per
 // wave, with next to nothing live across it, the kernel keeps its 64 VGPRs / 73 SGPRs and needs no scratch.
 __device__ __attribute__((noinline)) void file_blocks(const uint8_t *__restrict__ block_masks, int32_t *__restrict__ block_order, int bo_cap,
-                                                      int n_tiles, int tile, int start, int last)
+                                                      int n_tiles, int grid_x, int tile, int start, int last)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int kept = last;
@@ -140,8 +140,8 @@ __device__ __attribute__((noinline)) void file_blocks(const uint8_t *__restrict_
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
     if ((lane & 31) == 0) {
-        const int tpb = (n_tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS, band = tile / tpb;
-        const int q = (band * GSR_BO_CLASSES + gsr_bo_class(hits)) * GSR_BO_SHARDS + ((tile - band * tpb) & (GSR_BO_SHARDS - 1));
+        const int band = gsr_bo_band(tile, n_tiles, grid_x);
+        const int q = (band * GSR_BO_CLASSES + gsr_bo_class(hits)) * GSR_BO_SHARDS + ((tile - band * gsr_bo_tiles_per_band(n_tiles, grid_x)) & (GSR_BO_SHARDS - 1));
         const int pos = atomicAdd(&block_order[q], 1);
         if (pos < bo_cap) block_order[GSR_BO_HEADER + (size_t)q * bo_cap + pos] = tile * 8 + blk;
     }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         inv_depth[px] = cd;
     }
     if (tile_cost && lane == 0) tile_cost[tile * 4 + wv] = (min(walked, 0x7FFF) << 16) | min(staged, 0xFFFF);
-    if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, tile, start, last);
+    if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, grid_x, tile, start, last);
     TL(6)
     TL_FLUSH
 }
@@ -420,7 +420,7 @@ hipError_t gsr_launch_blend_forward(const CamK &cam, const int32_t *ranges, cons
     const int grid = (gsr_fwd_xcd_map ? 8 * ((tiles + 7) / 8) : tiles) + clear_wgs;
     hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(256), 0, s, cam.W, cam.H, cam.grid_x, cam.bg[0], cam.bg[1], cam.bg[2],
                        ranges, point_list, rec, img.image, img.inv_depth, img.final_T, img.n_contrib, block_masks, gsr_fwd_xcd_map, tiles,
-                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles), reinterpret_cast<float4 *>(clear), clear_n4, clear_wgs,
+                       block_masks ? block_order : nullptr, gsr_bo_cap(tiles, cam.grid_x), reinterpret_cast<float4 *>(clear), clear_n4, clear_wgs,
                        gsr_fwd_xcd_map ? nullptr : tile_order, tile_cost);
     return hipGetLastError();
 }

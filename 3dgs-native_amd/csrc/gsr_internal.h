@@ -175,9 +175,32 @@ hipError_t gsr_launch_expand_blocks(const GeomWs &ws, void *tile_items, int64_t 
 // rounds, 164 -> 154 us for 5 us more in the forward); at 1920x1080 (65 280 blocks, 8 rounds) the blend gains 2 % and the filing
 // costs the forward more than that, so larger images keep the plain band order.
 #define GSR_BO_MAX_TILES 4096
-static inline int gsr_bo_tiles_per_band(int tiles) { return (tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS; }
-static inline int gsr_bo_cap(int tiles) { return 8 * ((gsr_bo_tiles_per_band(tiles) + GSR_BO_SHARDS - 1) / GSR_BO_SHARDS); }
-static inline size_t gsr_bo_ints(int tiles) { return GSR_BO_HEADER + (size_t)GSR_BO_QUEUES * (size_t)gsr_bo_cap(tiles); }
+// Which band (= XCD) a tile belongs to.  GSR_BO_ROWS = 0: eight bands of consecutive tiles (an eighth of the image each: the XCDs
+// holding the image centre get more work than the others); GSR_BO_ROWS = G > 0: groups of G tile rows dealt to the bands in turn.
+#ifndef GSR_BO_ROWS
+#define GSR_BO_ROWS 0
+#endif
+__host__ __device__ static inline int gsr_bo_tiles_per_band(int tiles, int grid_x)
+{
+#if GSR_BO_ROWS > 0
+    const int grid_y = (tiles + grid_x - 1) / grid_x;
+    return ((grid_y + GSR_BO_BANDS * GSR_BO_ROWS - 1) / (GSR_BO_BANDS * GSR_BO_ROWS)) * GSR_BO_ROWS * grid_x; // an upper bound
+#else
+    (void)grid_x;
+    return (tiles + GSR_BO_BANDS - 1) / GSR_BO_BANDS;
+#endif
+}
+__host__ __device__ static inline int gsr_bo_band(int tile, int tiles, int grid_x)
+{
+#if GSR_BO_ROWS > 0
+    (void)tiles;
+    return ((tile / grid_x) / GSR_BO_ROWS) % GSR_BO_BANDS;
+#else
+    return tile / gsr_bo_tiles_per_band(tiles, grid_x);
+#endif
+}
+static inline int gsr_bo_cap(int tiles, int grid_x) { return 8 * ((gsr_bo_tiles_per_band(tiles, grid_x) + GSR_BO_SHARDS - 1) / GSR_BO_SHARDS); }
+static inline size_t gsr_bo_ints(int tiles, int grid_x) { return GSR_BO_HEADER + (size_t)GSR_BO_QUEUES * (size_t)gsr_bo_cap(tiles, grid_x); }
 // class of a block that keeps `hits` entries: four classes per octave from 8 entries up (class 0: fewer than 8)
 __host__ __device__ static inline int gsr_bo_class(int hits)
 {
