@@ -61,6 +61,12 @@ __device__ const int *g_fwd_order = nullptr; // experiment (tools/residency.py -
 
 namespace {
 
+// What a wave leaves for the next frame's tile order (gsr_internal.h "forward tile order"): 1 = its measured life in 100 MHz ticks
+// (the product since late round 4: C3 blend_fwd 98.0 -> 96.3 us in two same-box A/B rounds, the Lego trainer's 52.4 -> 49.0 us per
+// iteration, profiles/r04_s_fwd_cost_is_wave_life.txt), 0 = entries walked and staged (max of walked + staged / 2 ranked the tiles)
+#ifndef GSR_FWD_COST_LIFE
+#define GSR_FWD_COST_LIFE 1
+#endif
 constexpr int BATCH = 256;
 constexpr int NWAVES = 4;
 
@@ -191,6 +197,9 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int my_bits = 5 << ((wv >> 1) * 4 + (wv & 1)); // this wave's 8x8 block = the 8x4 blocks k0 and k0 + 2
 
+#if GSR_FWD_COST_LIFE
+    const unsigned long long t_born = wall_clock64();
+#endif
     const int2 range = *reinterpret_cast<const int2 *>(ranges + 2 * tile);
     const int start = range.x, end = range.y;
 
@@ -210,7 +219,8 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
     // the batch that was prefetched with it, then goes: the others' next wait for it falls under their walk of that batch.
     __shared__ int s_alive;
     if (tid == 0) s_alive = 0xF;
-    int alive_cur = 0xF, walked = 0; // walked: list entries this wave blended (its share of the tile's cost, for the next frame's order)
+    [[maybe_unused]] int walked = 0;
+    int alive_cur = 0xF; // walked: list entries this wave blended (its share of the tile's cost, for the next frame's order)
     const int wv_u = __builtin_amdgcn_readfirstlane(wv); // wave-uniform copy: the bookkeeping below stays in scalar registers
     auto rank_in = [&](int set) { return __popc(set & ((1 << wv_u) - 1)); };
     int nid = (start + tid < end) ? point_list[start + tid] : -1;
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         na = rp[0]; nb = rp[1];
         ncd = *reinterpret_cast<const float2 *>(rp + 2);
     }
-    int staged = 0; // list entries staged by the time this wave leaves
+    [[maybe_unused]] int staged = 0; // list entries staged by the time this wave leaves
     for (int base = start; base < end;) {
         __syncthreads(); // every surviving wave has walked the last batch (LDS reuse) and the leavers' bits are cleared
         TL(0)
@@ -369,7 +379,11 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(int W, int H, int gr
         image[3 * px + 2] = cb + T * bg2;
         inv_depth[px] = cd;
     }
+#if GSR_FWD_COST_LIFE
+    if (tile_cost && lane == 0) tile_cost[tile * 4 + wv] = (int)min((unsigned long long)0x7FFF, wall_clock64() - t_born) << 16;
+#else
     if (tile_cost && lane == 0) tile_cost[tile * 4 + wv] = (min(walked, 0x7FFF) << 16) | min(staged, 0xFFFF);
+#endif
     if (block_order) file_blocks(block_masks, block_order, bo_cap, n_tiles, grid_x, tile, start, last);
     TL(6)
     TL_FLUSH

@@ -6,7 +6,8 @@
 // The forward blend's tile order for THIS frame from the costs its waves left LAST frame (gsr_internal.h "forward tile order"), by
 // one 256-thread workgroup: the spare one at the end of preprocess_kernel's grid (a kernel of 145 VGPRs and 90 us: the order's 50
 // registers and 4 us cost it nothing; at the end of the expansion's grid they took that kernel from 8 to 5 workgroups per CU).
-// cost of a tile = the largest of its four waves' (entries walked + entries staged / 2); 64 classes on a scale set by the frame's
+// cost of a tile = the largest of its four waves' costs (a wave's life in ticks, in the `walked` field with `staged` = 0 -- or, with
+// GSR_FWD_COST_LIFE=0, entries walked + entries staged / 2); 64 classes on a scale set by the frame's
 // largest cost, heaviest class first; inside a class the tiles keep their order (wave by wave).  Any content of fwd_cost -- a
 // fresh workspace's garbage included -- yields a permutation of the tiles.
 // `lds`: GSR_FO_LDS_INTS ints of the caller's shared memory (the caller's own arrays, idle in this workgroup: no LDS of its own, so

@@ -52,7 +52,7 @@ struct GeomWs {
     int32_t *acc[2];      // [gsr_radix_acc_ints(N)] each: digit + super-block totals of a pass; consecutive passes alternate
     int32_t *acc_first;   // [gsr_radix_acc_ints(N)] behind acc[1]: the first ACTIVE depth pass's accumulators (filled beside the id-order scan)
     int32_t *sum4096;     // [N / 4096 + 1] tile pairs per 4096 depth-sorted Gaussians (depth_block_offsets_kernel; scan_tmp holds the 256-level)
-    int32_t *fwd_cost;    // [4 * GSR_FO_MAX_TILES] what the forward blend's waves walked / staged LAST frame ("forward tile order" below);
+    int32_t *fwd_cost;    // [4 * GSR_FO_MAX_TILES] what the forward blend's waves cost LAST frame ("forward tile order" below);
     int32_t *fwd_order;   // [GSR_FO_MAX_TILES]     this frame's dispatch order made from it (last in the workspace)
     size_t bytes;
 };
@@ -140,7 +140,8 @@ hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, con
 // --fwd-order: dispatch the tiles heaviest first by their MEASURED lives) takes the kernel from 113 to 94 us; by list length, which
 // is known before the blend, from 113 to 108 (rank correlation 0.05-0.16 with the life: saturation cuts every deep list at about the
 // same depth).  What does predict a tile's work is the tile's work a frame ago: a trainer comes back to its views, a viewer moves
-// its camera smoothly.  So every wave of the forward blend leaves behind what it walked and staged (fwd_cost, 4 ints per tile, in
+// its camera smoothly.  So every wave of the forward blend leaves behind its cost -- its measured life in 100 MHz ticks since late
+// round 4, the entries it walked and staged before (blend_fwd.hip GSR_FWD_COST_LIFE) -- (fwd_cost, 4 ints per tile, in
 // the caller's geom workspace, which persists between frames as long as the caller keeps it), and the next forward on that
 // workspace dispatches the tiles by cost class, heaviest first (fwd_order, made by a spare workgroup of preprocess_kernel
 // every frame from whatever fwd_cost holds -- garbage in a fresh workspace gives some permutation, never a wrong one).  Execution
