@@ -247,7 +247,8 @@ if "--fwd-order" in sys.argv:
     gx = (W + 15) // 16
     gy = tiles // gx
     timed_fwd(np.concatenate([np.arange(r, gy, 8) for r in range(8)])[:, None].repeat(gx, 1).__mul__(gx).__add__(np.arange(gx)[None, :]).reshape(-1), "tile rows interleaved by 8 (row r, r + 8, ...)")
-    # what the product's own predictor sees: the costs the waves left in the binning workspace (4 ints per tile: walked << 16 | staged)
+    # what the entry-count predictors would see (4 ints per tile: walked << 16 | staged): needs a census build made with
+    # EXTRA=-DGSR_FWD_COST_LIFE=0 -- the product's waves leave their measured life in the `walked` field since late round 4
     host = importlib.import_module("3dgs-native_amd._host")
     ws = [t for (kind, _, _), t in host._ws.items() if kind == "bin"][0]
     raw = ws[:16 * tiles].view(torch.int32).cpu().numpy().reshape(tiles, 4)
