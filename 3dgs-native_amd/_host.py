@@ -45,7 +45,28 @@ def host_f32(x, n):
     return a.astype(np.float32)
 
 
+_cams = {}
+
+
 def make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H):
+    """The GsrCamera of a call.  A trainer comes back to its views: the packed struct is kept under the BYTES of its inputs (numpy
+    arrays have no version counter, so identity would not do), which costs a quarter of packing it again."""
+    key = None
+    if type(viewmatrix) is np.ndarray and type(projmatrix) is np.ndarray and type(campos) is np.ndarray and type(background) is np.ndarray:
+        key = (viewmatrix.tobytes(), projmatrix.tobytes(), campos.tobytes(), background.tobytes(), viewmatrix.dtype.num, projmatrix.dtype.num,
+               campos.dtype.num, background.dtype.num, float(tan_fovx), float(tan_fovy), int(W), int(H))
+        cam = _cams.get(key)
+        if cam is not None:
+            return cam
+    cam = _pack_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H)
+    if key is not None:
+        if len(_cams) >= 4096:
+            _cams.clear()
+        _cams[key] = cam
+    return cam
+
+
+def _pack_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H):
     cam = _lib.GsrCamera()
     cam.view[:] = host_f32(viewmatrix, 16).tolist()    # float64 -> float32 once (reference forward.py:694-695)
     cam.proj[:] = host_f32(projmatrix, 16).tolist()
@@ -61,10 +82,10 @@ def make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, 
 _ws = {}
 
 
-def workspace(kind, nbytes, dev):
+def workspace(kind, nbytes, dev, stream=None):
     """Grow-only scratch buffer per (kind, device, stream): calls issued on different streams (several views in flight on
-    one GPU) never share scratch."""
-    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    one GPU) never share scratch.  `stream`: raw_stream(dev), when the caller has it already."""
+    key = (kind, dev.index, raw_stream(dev) if stream is None else stream)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
@@ -73,11 +94,42 @@ def workspace(kind, nbytes, dev):
 
 
 def ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+    """Device address for a `void *` struct field or argument (ctypes takes an int or None there): NULL for None or an empty tensor."""
+    return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream    # what torch.cuda.current_stream(dev).cuda_stream returns, without the Stream object
+except AttributeError:                                  # pragma: no cover
+    _raw_stream = None
+
+
+def raw_stream(dev):
+    """torch's current stream on `dev` as the integer a hipStream_t argument takes."""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def stream_ptr(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return raw_stream(dev)
+
+
+class on_device:
+    """`with torch.cuda.device(dev)` for the common case that `dev` is current already (then it costs one call, not a context switch)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def version_of(t):

@@ -98,13 +98,14 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     # likewise the forward's d(colour)/d(direction) sums (GsrGeom.sh_dir_grad) ride on its clamped_state tensor: used when shs
     # and means3D are the very tensors that forward read, with the same camera position and degree -- geom_backward_kernel then
     # reads 36 bytes per Gaussian instead of the 192 bytes of coefficients
+    cam = _host.make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H)
     sh_dir = None
     dir_tag = getattr(clamped, "_gsr_sh_dir", None)
     if dir_tag is not None:
         d_t, sh_ref, means_ref, campos_f, deg_f, sh_ver, means_ver = dir_tag
         if (sh_ref() is shs and means_ref() is means3D and _host.version_of(shs) == sh_ver and _host.version_of(means3D) == means_ver
                 and deg_f == int(degree) and d_t.device == dev
-                and campos_f == tuple(float(v) for v in _host.host_f32(campos, 3))):
+                and campos_f == tuple(cam.campos)):
             sh_dir = d_t
     backward.last_call_used_forward_sh_dir = sh_dir is not None     # for tests and debugging
     radii = _host.to_dev(radii, i32, dev, (-1,))
@@ -121,7 +122,6 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     n_contrib = _host.to_dev(n_contrib, i32, dev, (H, W))
     point_list = _host.to_dev(point_list, i32, dev, (-1,))
     D = point_list.shape[0]
-    cam = _host.make_camera(viewmatrix, projmatrix, campos, background, tan_fovx, tan_fovy, W, H)
 
     scene = _lib.GsrScene(N, _host.ptr(means), _host.ptr(sc), _host.ptr(rot), _host.ptr(op), _host.ptr(sh), int(degree),
                           float(scale_modifier), 1)
@@ -151,7 +151,8 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     dL_dscale = arena[o[1]:o[1] + 3 * N].view(N, 3)
     dL_drot = arena[o[2]:o[2] + 4 * N].view(N, 4)
     dL_dopacity = arena[o[3]:o[3] + N]
-    with torch.cuda.device(dev):
+    stream = _host.raw_stream(dev)
+    with _host.on_device(dev):
         # The workspace belongs to THIS call (the returned blend-stage gradients are views of it).  If the forward made one and
         # cleared its accumulators in its blend kernel -- and no backward has taken it yet -- it is that one; else a fresh one,
         # which the library clears itself.
@@ -180,14 +181,13 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
             # two halves: the view payload is complete after the blend half, so the caller's hook can start its exchange
             # (an asynchronous all-gather) while the per-Gaussian half still runs
             _lib.check(L.gsr_backward_blend(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
-                                            _host.ptr(payload), _host.ptr(ws), ws.numel(), _host.stream_ptr(dev)))
+                                            _host.ptr(payload), _host.ptr(ws), ws.numel(), stream))
             on_payload(payload)
             grads.dL_drgb = None
-            _lib.check(L.gsr_backward_geom(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(grads), _host.ptr(ws), ws.numel(),
-                                           _host.stream_ptr(dev)))
+            _lib.check(L.gsr_backward_geom(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(grads), _host.ptr(ws), ws.numel(), stream))
         else:
             _lib.check(L.gsr_backward(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img), _host.ptr(dpix),
-                                      C.byref(grads), _host.ptr(ws), ws.numel(), _host.stream_ptr(dev)))
+                                      C.byref(grads), _host.ptr(ws), ws.numel(), stream))
     return {
         "dL_dmean3D": dL_dmean3D, "dL_dcolor": dL_dcolor, "dL_dshs": dL_dsh, "dL_dopacity": dL_dopacity,
         "dL_dscale": dL_dscale, "dL_drot": dL_drot, "dL_dmean2D": dL_dmean2D, "dL_dconic": dL_dconic,

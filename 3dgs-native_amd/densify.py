@@ -59,7 +59,7 @@ def mark_candidates(params, pos_grad, grad_threshold, scene_extent, percent_dens
     if n_grad and not (pos_grad.is_cuda and pos_grad.dtype == torch.float32 and pos_grad.is_contiguous()):
         raise ValueError("densify: pos_grad must be a contiguous float32 device tensor")
     mask = torch.empty(n, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_densify_mark(C.byref(p), _host.ptr(pos_grad) if n_grad else None, min(n_grad, n), float(grad_threshold),
                                                float(scene_extent), float(percent_dense), _lib.MARK_SPLIT if split else _lib.MARK_CLONE,
                                                _host.ptr(mask), _host.stream_ptr(dev)))
@@ -72,7 +72,7 @@ def prune_mask(params, opacity_threshold):
     dev = params["positions"].device
     p = _params_struct(params, n)
     valid = torch.empty(n, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_prune_mark(C.byref(p), float(opacity_threshold), _host.ptr(valid), _host.stream_ptr(dev)))
     return valid
 
@@ -81,7 +81,7 @@ def split_removal_mask(split_mask, n_total):
     """mark_split_originals_for_removal + invert_mask (train.py:547-576): 1 = keep."""
     dev = split_mask.device
     valid = torch.empty(n_total, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_split_removal_mask(n_total, int(split_mask.numel()), _host.ptr(split_mask), _host.ptr(valid),
                                                      _host.stream_ptr(dev)))
     return valid
@@ -96,7 +96,7 @@ def exclusive_scan(mask):
     nbytes = int(L.gsr_mask_scan_workspace_bytes(n))
     scratch = _host.workspace("mask_scan", nbytes, dev)
     count = C.c_int32(0)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(L.gsr_mask_scan(n, _host.ptr(mask), _host.ptr(prefix), C.byref(count), _host.ptr(scratch), nbytes, _host.stream_ptr(dev)))
     return prefix, int(count.value)
 
@@ -107,7 +107,7 @@ def clone_gaussians(params, mask, prefix, total, noise_scale=0.01):
     dev = params["positions"].device
     out = alloc_params(n + total, dev)
     pin, pout = _params_struct(params, n), _params_struct(out, n + total)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_clone_gaussians(C.byref(pin), _host.ptr(mask), _host.ptr(prefix), float(noise_scale), C.byref(pout),
                                                   _host.stream_ptr(dev)))
     return out
@@ -119,7 +119,7 @@ def split_gaussians(params, mask, prefix, total, n_split=2, scale_factor=0.8):
     dev = params["positions"].device
     out = alloc_params(n + total * n_split, dev)
     pin, pout = _params_struct(params, n), _params_struct(out, n + total * n_split)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_split_gaussians(C.byref(pin), _host.ptr(mask), _host.ptr(prefix), int(n_split), float(scale_factor),
                                                   C.byref(pout), _host.stream_ptr(dev)))
     return out
@@ -131,7 +131,7 @@ def compact_gaussians(params, valid, prefix, count):
     dev = params["positions"].device
     out = alloc_params(count, dev)
     pin, pout = _params_struct(params, n), _params_struct(out, count)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_compact_gaussians(C.byref(pin), _host.ptr(valid), _host.ptr(prefix), C.byref(pout), _host.stream_ptr(dev)))
     return out
 
@@ -139,7 +139,7 @@ def compact_gaussians(params, valid, prefix, count):
 def reset_opacities(opacities, max_opacity=0.01):
     """reset_opacities (optimizer.py:141-156), in place."""
     dev = opacities.device
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_reset_opacities(int(opacities.numel()), float(max_opacity), _host.ptr(opacities), _host.stream_ptr(dev)))
     _host.written_in_place(opacities)
 
@@ -152,7 +152,7 @@ def init_gaussian_params(num_points, init_scale=0.1, device="cuda"):
         dev = torch.device("cuda", torch.cuda.current_device())
     out = alloc_params(int(num_points), dev)
     p = _params_struct(out, int(num_points))
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(_lib.lib().gsr_init_gaussians(C.byref(p), float(init_scale), _host.stream_ptr(dev)))
     return out
 

@@ -260,7 +260,7 @@ def sh_gradients_from_views(means3D, payloads, degree=3, average=True, out=None,
     if out is None:
         out = torch.empty((n * 16, 3), dtype=torch.float32, device=dev)
     factor = float(scale) if scale is not None else (1.0 / len(rows) if average else 1.0)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         # the kernel takes at most GSR_MAX_VIEWS payload rows per call: larger batches are rebuilt in chunks and summed
         tmp = None
         for c0 in range(0, len(rows), MAX_VIEWS_PER_CALL):

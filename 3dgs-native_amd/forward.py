@@ -70,10 +70,10 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
     final_Ts, n_contrib = e((H, W), f32), e((H, W), i32)
     img = _lib.GsrImage(_host.ptr(image), _host.ptr(depth_image), _host.ptr(final_Ts), _host.ptr(n_contrib))
     ranges = e((gx * gy, 2), i32)
-    stream = _host.stream_ptr(dev)
+    stream = _host.raw_stream(dev)
 
-    with torch.cuda.device(dev):
-        gws = _host.workspace("geom", L.gsr_geom_workspace_bytes(N), dev)
+    with _host.on_device(dev):
+        gws = _host.workspace("geom", L.gsr_geom_workspace_bytes(N), dev, stream)
         D = C.c_int64(0)
         _lib.check(L.gsr_forward_count(C.byref(scene), C.byref(cam), C.byref(geom), _host.ptr(gws), gws.numel(),
                                        C.byref(D), stream))
@@ -94,7 +94,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
             bwd_ws = e((int(L.gsr_backward_workspace_bytes(N, D, W, H)),), torch.uint8)
         binning = _lib.GsrBinning(D, _host.ptr(point_list), _host.ptr(ranges), _host.ptr(block_masks), _host.ptr(block_order),
                                   _host.ptr(bwd_ws), 0)
-        bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev)
+        bws = _host.workspace("bin", L.gsr_binning_workspace_bytes(N, D, W, H), dev, stream)
         _lib.check(L.gsr_forward_render(C.byref(scene), C.byref(cam), C.byref(geom), C.byref(binning), C.byref(img),
                                         _host.ptr(gws), gws.numel(), _host.ptr(bws), bws.numel(), stream))
     # Let a following backward() use the records as they are: the tag rides on the means2D view (the reference's callers re-pack
@@ -111,7 +111,7 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
             # sh / means3D tensors, this camera position and this degree
             # -- and only while neither has been written in place since (torch's version counters; the library's own in-place
             # writers, Adam and the opacity reset, bump them too: _host.written_in_place)
-            clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(float(v) for v in cam.campos), int(degree),
+            clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(cam.campos), int(degree),
                                          sh._version, means3D._version)
         owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
         point_list._gsr_block_masks = (block_masks, {k: (weakref.ref(v), v._version) for k, v in owners.items()}, block_order)

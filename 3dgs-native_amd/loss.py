@@ -24,7 +24,7 @@ def l1_loss_and_gradients(rendered, target, lambda_dssim=0.0, want_grad=True, lo
         raise ValueError("l1_loss_and_gradients: loss_out must be a 1-element float32 device tensor")
     loss_sum = torch.empty(1, dtype=torch.float32, device=dev) if loss_out is None else loss_out
     l1_weight = (1.0 - float(lambda_dssim)) / (H * W * 3.0)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(L.gsr_l1_loss_grad(_host.ptr(r), _host.ptr(t), _host.ptr(grad), _host.ptr(loss_sum), W, H, l1_weight,
                                       _host.stream_ptr(dev)))
     return loss_sum, grad
@@ -52,7 +52,7 @@ def ssim(rendered, target):
     r = r.reshape(H, W, 3)
     t = _host.to_dev(target, torch.float32, dev, (H, W, 3))
     acc = torch.empty(1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(L.gsr_ssim(_host.ptr(r), _host.ptr(t), _host.ptr(acc), W, H, _host.stream_ptr(dev)))
     return float(acc.item()) / (W * H)
 
@@ -67,6 +67,6 @@ def depth_loss(rendered_depth, target_depth, depth_mask):
     t = _host.to_dev(target_depth, torch.float32, dev, (H, W))
     m = _host.to_dev(depth_mask, torch.float32, dev, (H, W))
     acc = torch.empty(1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         _lib.check(L.gsr_depth_loss(_host.ptr(r), _host.ptr(t), _host.ptr(m), _host.ptr(acc), W, H, _host.stream_ptr(dev)))
     return float(acc.item()) / (W * H)

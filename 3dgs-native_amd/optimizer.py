@@ -57,7 +57,7 @@ def adam_update(params, grads, m, v, lrs=None, beta1=0.9, beta2=0.999, epsilon=1
         g = None if (k == "shs" and rows is not None) else grads[k]
         groups.append(_lib.GsrAdamGroup(_host.ptr(params[k]), _host.ptr(g), _host.ptr(m[k]), _host.ptr(v[k]), float(lrs[k])))
     a = _lib.GsrAdam(n, groups[0], groups[1], groups[2], groups[3], groups[4], float(beta1), float(beta2), float(epsilon), int(iteration))
-    with torch.cuda.device(dev):
+    with _host.on_device(dev):
         if rows is None:
             _lib.check(L.gsr_adam_update(C.byref(a), _host.stream_ptr(dev)))
         else:
