@@ -467,7 +467,8 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     auto pass_bits = [&](int pass, int shift) { return std::max(4, (tb - shift + (npass - pass) - 1) / (npass - pass)); };
     // the block order (forward -> backward scratch): header cleared here; filed by the blend below unless the image is large
     int32_t *order = binning->block_masks ? binning->block_order : nullptr;
-    const bool file_order = order && tiles <= GSR_BO_MAX_TILES;
+    // (and not for a frame whose backward will take 8x8 blocks, which run in band order: the `filed` flag then stays 0)
+    const bool file_order = order && tiles <= GSR_BO_MAX_TILES && gsr_bwd_block_px(N, D, tiles) == 32;
     const bool by_gaussian = (gsr_debug_flags & 512) != 0; // GSR_DEBUG bit 9: the expansion by Gaussian + the first pass's own histogram kernel (tests, A/B)
     // the forward blend's tiles by last frame's cost classes (gsr_internal.h "forward tile order"): the table was made by the spare
     // workgroup of this frame's preprocess (gsr_forward_count, same condition), so it is never stale or foreign

@@ -626,8 +626,7 @@ hipError_t gsr_launch_blend_backward_splat(const CamK &cam, const int32_t *range
     // cross at D / N of 18-22 (8x4 is 10-25 % faster below 13, 8x8 is 14-24 % faster above 40); images of more than
     // GSR_BO_MAX_TILES tiles, whose 8x4 blocks the forward does not file by cost, cross at 4-5 already (1080p: 8x8 is 5-24 %
     // faster from 5.4 up).  GSR_BWD_BLOCK = 32, 64 or 16 (4x4) forces one size.
-    const int64_t wide_from = tiles > GSR_BO_MAX_TILES ? GSR_BWD_WIDE_PAIRS_UNFILED : GSR_BWD_WIDE_PAIRS;
-    const int block_px = gsr_bwd_block > 0 ? gsr_bwd_block : (D >= wide_from * N ? 64 : 32);
+    const int block_px = gsr_bwd_block_px(N, D, tiles);
     switch (block_px) {
     case 16: LAUNCH(4, 4, false); break;
     case 64: if (block_masks) LAUNCH(8, 8, true); else LAUNCH(8, 8, false); break;

@@ -258,3 +258,10 @@ extern int gsr_bwd_xcd_map;        // GSR_BWD_XCD: a tile's blocks of the backwa
 extern int gsr_bwd_block;          // GSR_BWD_BLOCK: pixels per wave in the Gaussian-parallel backward (64, 32, 16); 0 = per frame
 #define GSR_BWD_WIDE_PAIRS 20         // D / N from which the backward blend takes 8x8 blocks instead of 8x4 ...
 #define GSR_BWD_WIDE_PAIRS_UNFILED 5  // ... and for images of more than GSR_BO_MAX_TILES tiles (no block order for 8x4 there)
+// pixels per backward-blend wave for a frame of N Gaussians, D tile pairs, `tiles` tiles (blend_bwd_splat.hip, the launcher): the
+// forward asks too -- it files the 8x4 blocks by cost only for a frame whose backward will run 8x4 blocks
+static inline int gsr_bwd_block_px(int64_t N, int64_t D, int tiles)
+{
+    if (gsr_bwd_block > 0) return gsr_bwd_block;
+    return D >= (int64_t)(tiles > GSR_BO_MAX_TILES ? GSR_BWD_WIDE_PAIRS_UNFILED : GSR_BWD_WIDE_PAIRS) * N ? 64 : 32;
+}
