@@ -241,6 +241,32 @@ def test_torch_inputs_stay_on_device(oracle, cameras, scenes):
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2]["point_list"], ref[2]["point_list"])
 
 
+def test_camera_arrays_written_in_place_between_calls(oracle, cameras, scenes):
+    """The host keeps packed camera structs by the BYTES of the arrays they were made from (numpy arrays carry no version counter):
+    a caller who moves its camera by writing into the same arrays, or swaps the background, gets the new view -- forward and backward
+    against the oracle fed the same arrays at each point."""
+    gsr = pkg()
+    W = H = 96
+    sc = scenes.synthetic_scene(1500, 0.06, 0.5, 21)
+    cam = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in lego_camera(cameras, frame=0, width=W, height=H).items()}
+    other = lego_camera(cameras, frame=5, width=W, height=H)
+    kw = render_kwargs(sc, cam, width=W, height=H, bg=(0.0, 0.0, 0.0))
+    dpix = _pixel_grad(H, W)
+    first = gsr.render_gaussians(**kw)[0].cpu().numpy()
+    for step in range(2):
+        if step == 0:      # the same array objects, new contents
+            for k in ("world_to_camera", "full_proj_matrix", "camera_center"):
+                cam[k][...] = other[k]
+        else:              # and a background written in place
+            kw["background"][...] = (0.2, 0.5, 0.8)
+        got = gsr.render_gaussians(**kw)
+        ref = oracle.render_gaussians(**kw)
+        parity.compare_forward(got, ref, None)
+        assert np.abs(got[0].cpu().numpy() - first).max() > 1e-2      # it IS another picture
+        bkw = backward_kwargs(sc, cam, kw, ref[2], dpix)
+        parity.compare_backward(gsr.backward(**bkw), oracle.backward(**bkw), None)
+
+
 def test_workspace_and_capacity_errors(cameras, scenes):
     """Too-small scratch buffers are refused with GSR_E_WORKSPACE (mapped to RuntimeError), not overrun."""
     import ctypes as C
