@@ -133,7 +133,9 @@ typedef struct GsrBinning {
                              entries the backward will keep for the block; gsr_backward, given the SAME array back unmodified,
                              starts the heaviest blocks first (its blend kernel's last-started waves decide when it ends:
                              164 -> 154 us at 800x800 / 1 M Gaussians).  Read-only on the backward side.  Execution order
-                             only: results are the same up to float-atomic order. */
+                             only: results are the same up to float-atomic order.  Nothing is filed (a flag in the array says
+                             so) for images of more than 4 096 tiles, nor for a frame of large splats (D >= 20 N), whose
+                             backward blend runs 8x8-pixel blocks in plain band order. */
     void *backward_ws;    /* optional: the workspace the caller will give gsr_backward (>= gsr_backward_workspace_bytes).  Handed to
                              gsr_forward_render, the forward blend kernel's spare workgroups clear the accumulator records in it
                              while that kernel drains -- the 64 bytes per Gaussian gsr_backward otherwise clears in a launch of
