@@ -23,7 +23,7 @@ __device__ __forceinline__ void fwd_order_block(const int32_t *__restrict__ fwd_
         auto one = [](int v) { const int walked = (v >> 16) & 0x7FFF, staged = v & 0xFFFF; return walked + (staged >> 1); };
         return max(max(one(c.x), one(c.y)), max(one(c.z), one(c.w)));
     };
-    s_cnt[w][tid & 63] = 0;
+    for (int c = tid & 63; c < GSR_FO_CLASSES; c += 64) s_cnt[w][c] = 0;
     constexpr int PER = GSR_FO_MAX_TILES / 256; // tiles per thread, kept in registers: tile = k * 256 + tid
     int cost[PER], mx = 1;
 #pragma unroll
@@ -45,17 +45,24 @@ __device__ __forceinline__ void fwd_order_block(const int32_t *__restrict__ fwd_
         rank[k] = cost[k] >= 0 ? atomicAdd(&s_cnt[w][cls[k]], 1) : 0; // position among this wave's tiles of the class (k ascending)
     }
     __syncthreads();
+    static_assert(GSR_FO_CLASSES <= 256 && GSR_FO_CLASSES % 64 == 0, "one thread per class, whole waves");
+    int run = 0, incl = 0;
     if (tid < GSR_FO_CLASSES) { // per class: the four waves' counts -> their offsets inside the class; then the classes' first slots
-        int run = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const int c = s_cnt[q][tid]; s_cnt[q][tid] = run; run += c; }
-        int incl = run;
+        incl = run;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(incl, d, 64);
-            if (tid >= d) incl += up;
+            if ((tid & 63) >= d) incl += up;
         }
-        s_base[tid] = incl - run;
+        if ((tid & 63) == 63) s_max[w] = incl; // (s_max is free again: every thread has read it)
+    }
+    __syncthreads();
+    if (tid < GSR_FO_CLASSES) {
+        int before = 0;
+        for (int q = 0; q < w; ++q) before += s_max[q];
+        s_base[tid] = before + incl - run;
     }
     __syncthreads();
 #pragma unroll

@@ -34,7 +34,9 @@ static inline int64_t gsr_div_up(int64_t a, int64_t b) { return (a + b - 1) / b;
 static inline size_t gsr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 #define GSR_FO_MAX_TILES 4096  // forward tile order (see below): images of at most this many tiles
+#ifndef GSR_FO_CLASSES
 #define GSR_FO_CLASSES 64
+#endif
 // ---- layout of the geom workspace (persists from gsr_forward_count to gsr_forward_render) ----
 struct GeomWs {
     BlendRec *rec;        // [N]
