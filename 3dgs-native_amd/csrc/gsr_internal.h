@@ -100,6 +100,12 @@ bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes
 #ifndef GSR_RADIX_CHUNK
 #define GSR_RADIX_CHUNK 4096
 #endif
+// Threads per scatter workgroup on the large-chunk path.  512 (late round 4): the same 4096-item chunk as 8 waves of 8 items per thread
+// instead of 4 waves of 16 -- 63 VGPRs instead of 94, 32 waves per CU instead of 20: tile partition 72.2 -> 70.0 us at C3, 331 -> 320 us at
+// C5 (profiles/r04_w_scatter_workgroup_shapes.txt; 1024 threads, and 6144- / 8192-item chunks with 512, are slower or move the time into the expansion)
+#ifndef GSR_RADIX_WG
+#define GSR_RADIX_WG 512
+#endif
 #define GSR_RADIX_SMALL_CHUNK 1024      // chunk used when n <= GSR_RADIX_SMALL_N (more, smaller blocks)
 #define GSR_RADIX_SMALL_N (4 << 20)
 static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_N ? (n + GSR_RADIX_SMALL_CHUNK - 1) / GSR_RADIX_SMALL_CHUNK : (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }

@@ -61,6 +61,25 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int *lds4 /* >= 4 ints
     return s + add;
 }
 
+// the same across a block of NW waves (every thread calls it; lds >= NW ints)
+template <int NW> __device__ __forceinline__ int block_incl_scan_nw(int v, int *lds, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int s = wave_incl_scan(v);
+    if (lane == 63) lds[w] = s;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        int c = lds[k];
+        if (k < w) add += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return s + add;
+}
+
 // ---------------------------------------------------------------------------------------------
 // device-wide scan in two kernels: per-wave sums -> per-wave rescan (each wave first adds up the sums before it).
 // The unit of work is a WAVE owning 1024 consecutive items, walked in 16 rounds of 64 so every load and
@@ -425,17 +444,18 @@ struct ScatterFinal {
     int id_shift;
 };
 
-template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ acc,
                                                             int64_t n, int shift, int nb, int sb, bool prefixed, int32_t *__restrict__ zero_acc,
                                                             int zero_n, ScatterCarry carry, ScatterFinal fin, DepthPass dp)
 {
-    constexpr int CHUNK = 256 * RADIX_ITEMS;
+    constexpr int CHUNK = THREADS * RADIX_ITEMS;
+    constexpr int NW = THREADS / 64; // waves per workgroup (GSR_RADIX_WIDE_WG: 8 waves of 8 items instead of 4 of 16 for the same chunk)
     constexpr int RADIX = 1 << BITS;
     __shared__ ItemT s_items[CHUNK];    // items reordered by digit
     __shared__ unsigned long long s_rect[CARRY ? CHUNK : 1]; // CARRY: the items' rectangles (raw bits), reordered with them
-    __shared__ int s_wcnt[4][RADIX];               // per-wave digit counts -> per-wave start offsets
+    __shared__ int s_wcnt[NW][RADIX];              // per-wave digit counts -> per-wave start offsets
     __shared__ int s_before[RADIX];                // items of each digit in earlier blocks
     __shared__ int s_total[RADIX];                 // items of each digit in all blocks
     // thread d reads [d] of the two arrays above into registers before it writes [d] of these two: they share the space
@@ -443,7 +463,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     int *const s_dstart = s_total;                 // first LDS slot of each digit
     int *const s_gbase = s_before;                 // global position of the block's first item of each digit
     __shared__ int s_dcnt[FINAL ? RADIX : 1];      // FINAL: items of each digit in this block
-    __shared__ int s_tmp[4];
+    __shared__ int s_tmp[NW];
     __shared__ int s_valid_n;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -453,13 +473,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
 
     if (tid < RADIX) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_wcnt[k][tid] = 0;
+        for (int k = 0; k < NW; ++k) s_wcnt[k][tid] = 0;
         s_before[tid] = 0;
         s_total[tid] = 0;
     }
     // the next pass's accumulators (see radix_hist_kernel) are cleared here: nothing reads them before that pass's histogram
     // (also by a depth pass that then finds it has nothing to sort)
-    for (int z = blockIdx.x * 256 + tid; z < zero_n; z += gridDim.x * 256) zero_acc[z] = 0;
+    for (int z = blockIdx.x * THREADS + tid; z < zero_n; z += gridDim.x * THREADS) zero_acc[z] = 0;
     uint32_t kmin = 0u, krange = 0u;
     bool drop_culled = false;
     int64_t n_load = n; // items readable in `in` (the index clamp of the loads)
@@ -479,7 +499,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         if constexpr (CARRY) {
             // the depth-order scan runs over all N counts: those behind the survivors are zero
             const int64_t z0 = max((int64_t)c.n_vis, block_base), z1 = min(block_base + (int64_t)CHUNK, carry.n_total);
-            for (int64_t z = z0 + tid; z < z1; z += 256) carry.cnt_sorted[z] = 0;
+            for (int64_t z = z0 + tid; z < z1; z += THREADS) carry.cnt_sorted[z] = 0;
         }
         if (block_base >= n) return;
     }
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     int4 before_part = make_int4(0, 0, 0, 0), total_part = make_int4(0, 0, 0, 0);
     constexpr int TPT = RADIX / 4;  // threads per term: each adds four consecutive digits (one 16-byte load)
     {
-        constexpr int GROUPS = 256 / TPT;
+        constexpr int GROUPS = THREADS / TPT;
         const int d4 = (tid % TPT) * 4, g = tid / TPT, my_sb = blockIdx.x / sb, nsuper = (nb + sb - 1) / sb;
         // (two plain strided loops, so that each unrolled body issues its loads together)
         const int32_t *rows = hist + (size_t)my_sb * sb * RADIX + d4; // the earlier blocks of the own super-block
@@ -591,20 +611,20 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
         int run = 0;
         if (own) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NW; ++k) {
                 const int c = s_wcnt[k][d];
                 s_wcnt[k][d] = run;
                 run += c;
             }
         }
         int tot;
-        const int inc = block_incl_scan_256(run, s_tmp, &tot);
+        const int inc = block_incl_scan_nw<NW>(run, s_tmp, &tot);
         if (tid == 0) s_valid_n = tot; // items of this block that take part (all of its chunk, unless culled ones were dropped)
         // digit base over the whole array = sum of totals of smaller digits; then the items of this digit in earlier blocks:
         // whole super-blocks from the accumulators, the rest of the own super-block from the block histograms
         const int td = own ? s_total[d] : 0;
         const int before = own ? s_before[d] : 0;
-        const int tinc = block_incl_scan_256(td, s_tmp, &tot);
+        const int tinc = block_incl_scan_nw<NW>(td, s_tmp, &tot);
         if (own) {
             s_dstart[d] = inc - run;
             s_gbase[d] = tinc - td + before;
@@ -633,7 +653,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const ItemT *__restr
     const int valid_n = s_valid_n;
 #pragma unroll 4
     for (int r = 0; r < RADIX_ITEMS; ++r) {
-        const int slot = r * 256 + tid;
+        const int slot = r * THREADS + tid;
         if (slot < valid_n) {
             const ItemT it = s_items[slot];
             const int d = radix_digit<DEPTH, BITS>(it, shift, kmin, krange);
@@ -1187,8 +1207,8 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
                            n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
         if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n,
-                           shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / GSR_RADIX_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_WG>), dim3(g.nb), dim3(GSR_RADIX_WG), 0, s, in, out,
+                           hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
     if constexpr (FINAL)
         hipLaunchKernelGGL(ranges_fixup_kernel, dim3(1 << BITS), dim3(1024), 0, s, fin.edge_first, fin.edge_last, fin.edge_pos, acc, g.nb, 1 << BITS,
