@@ -106,9 +106,21 @@ bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes
 #ifndef GSR_RADIX_WG
 #define GSR_RADIX_WG 512
 #endif
-#define GSR_RADIX_SMALL_CHUNK 1024      // chunk used when n <= GSR_RADIX_SMALL_N (more, smaller blocks)
+// Three sizes of pass (scan_sort.hip pass_geom): up to GSR_RADIX_TINY_N items 1024-item chunks in 256-thread workgroups (many small
+// blocks keep the chip busy: at 100 k items the 2048-item form costs the depth sort 2 us); up to GSR_RADIX_SMALL_N 2048-item chunks in
+// 512-thread workgroups, four items per thread as before but half the blocks, hence half the histogram rows every block sums (late
+// round 4: depth sort 63.1 -> 56.8 us at C3, profiles/r04_w_scatter_workgroup_shapes.txt); above that GSR_RADIX_CHUNK.
+#define GSR_RADIX_TINY_CHUNK 1024
+#define GSR_RADIX_TINY_N (1 << 19)
+#ifndef GSR_RADIX_SMALL_WG
+#define GSR_RADIX_SMALL_WG 512
+#endif
+#ifndef GSR_RADIX_SMALL_CHUNK
+#define GSR_RADIX_SMALL_CHUNK 2048
+#endif
 #define GSR_RADIX_SMALL_N (4 << 20)
-static inline int64_t gsr_radix_blocks(int64_t n) { return n <= GSR_RADIX_SMALL_N ? (n + GSR_RADIX_SMALL_CHUNK - 1) / GSR_RADIX_SMALL_CHUNK : (n + GSR_RADIX_CHUNK - 1) / GSR_RADIX_CHUNK; }
+static inline int gsr_radix_chunk(int64_t n) { return n <= GSR_RADIX_TINY_N ? GSR_RADIX_TINY_CHUNK : n <= GSR_RADIX_SMALL_N ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK; }
+static inline int64_t gsr_radix_blocks(int64_t n) { const int c = gsr_radix_chunk(n); return (n + c - 1) / c; }
 // A pass's blocks are grouped into super-blocks of about sqrt(nb) blocks; its accumulators are 256 digit totals followed by
 // 256 per super-block (scan_sort.hip, radix_hist_kernel).
 #define GSR_RADIX_PREFIX_NB 2048 // passes over more blocks than this scan their super-block rows first (radix_superscan_kernel)

@@ -1175,14 +1175,16 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
 
 // chunk size and super-block size of a pass over n items (gsr_internal.h: gsr_radix_blocks, gsr_radix_sb)
 struct PassGeom {
-    bool small, prefixed;
-    int nb, sb;
+    int tier;      // 0: GSR_RADIX_TINY_CHUNK, 1: GSR_RADIX_SMALL_CHUNK, 2: GSR_RADIX_CHUNK (gsr_internal.h)
+    bool prefixed;
+    int nb, sb, chunk;
 };
 static PassGeom pass_geom(int64_t n)
 {
     PassGeom g;
-    g.small = n <= GSR_RADIX_SMALL_N && !(gsr_debug_flags & 64); // GSR_DEBUG bit 6: take the large-n path at any n (tests)
-    g.nb = (int)gsr_div_up(n, g.small ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK);
+    g.tier = (gsr_debug_flags & 64) ? 2 : n <= GSR_RADIX_TINY_N ? 0 : n <= GSR_RADIX_SMALL_N ? 1 : 2; // GSR_DEBUG bit 6: the large-n path at any n (tests)
+    g.chunk = g.tier == 0 ? GSR_RADIX_TINY_CHUNK : g.tier == 1 ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK;
+    g.nb = (int)gsr_div_up(n, g.chunk);
     g.sb = gsr_radix_sb(g.nb);
     g.prefixed = g.nb > GSR_RADIX_PREFIX_NB || (gsr_debug_flags & 128); // GSR_DEBUG bit 7: at any block count (tests)
     return g;
@@ -1196,17 +1198,21 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
     // (a skipped depth pass leaves its accumulator rows zero: the super-block scan of a many-block pass then scans zeros)
     // hist_ready: the kernel that produced `in` left this pass's block histograms and super-block sums (expand_blocks_kernel)
     if (hist_ready) {
-    } else if (g.small) {
+    } else if (g.tier == 0) {
+        hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_TINY_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
+    } else if (g.tier == 1) {
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
     } else {
         hipLaunchKernelGGL((radix_hist_kernel<GSR_RADIX_CHUNK / 256, BITS, ItemT, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, hist, acc, n, shift, g.sb, dp);
     }
-    if (g.small) {
-        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc,
-                           n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
+    if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
+    if (g.tier == 0) {
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_TINY_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH, 256>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n, shift,
+                           g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
+    } else if (g.tier == 1) {
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / GSR_RADIX_SMALL_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_SMALL_WG>), dim3(g.nb), dim3(GSR_RADIX_SMALL_WG),
+                           0, s, in, out, hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
         hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / GSR_RADIX_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_WG>), dim3(g.nb), dim3(GSR_RADIX_WG), 0, s, in, out,
                            hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
@@ -1267,12 +1273,13 @@ hipError_t gsr_launch_scan_ctl_hist(const int32_t *tiles_touched, int32_t *point
     const int nb_scan = ((int)gsr_div_up(n, GSR_SCAN_WAVE_ITEMS) + 3) / 4, nblk = (int)gsr_div_up(n, 256), n_ctl = gsr_depth_ctl_wgs(n);
     const PassGeom g = pass_geom(n);
     DepthCtlRaw *ctl = (DepthCtlRaw *)ws.depth_ctl;
-    if (g.small)
-        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_SMALL_CHUNK / 256>), dim3(nb_scan + n_ctl + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
-                           total_out, ws.blk_minmax, nblk, ctl, n_ctl, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
-    else
-        hipLaunchKernelGGL((scan_ctl_hist_kernel<GSR_RADIX_CHUNK / 256>), dim3(nb_scan + n_ctl + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n,
-                           total_out, ws.blk_minmax, nblk, ctl, n_ctl, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb);
+#define GSR_SCH(CH)                                                                                                                                    \
+    hipLaunchKernelGGL((scan_ctl_hist_kernel<(CH) / 256>), dim3(nb_scan + n_ctl + g.nb), dim3(256), 0, s, tiles_touched, ws.scan_tmp, point_offsets, n, \
+                       total_out, ws.blk_minmax, nblk, ctl, n_ctl, nb_scan, ws.depth_item, ws.hist, ws.acc_first, g.sb)
+    if (g.tier == 0) GSR_SCH(GSR_RADIX_TINY_CHUNK);
+    else if (g.tier == 1) GSR_SCH(GSR_RADIX_SMALL_CHUNK);
+    else GSR_SCH(GSR_RADIX_CHUNK);
+#undef GSR_SCH
     return hipGetLastError();
 }
 
@@ -1341,7 +1348,7 @@ hipError_t gsr_launch_expand_blocks(const GeomWs &ws, void *tile_items, int64_t 
 {
     if (n <= 0 || D <= 0) return hipSuccess;
     const PassGeom g = pass_geom(D);
-    const int chunk = g.small ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK, nsum = (int)gsr_div_up(n, 256);
+    const int chunk = g.chunk, nsum = (int)gsr_div_up(n, 256);
     if (item_bytes == 4)
         hipLaunchKernelGGL(expand_blocks_kernel<uint32_t>, dim3(g.nb), dim3(256), 0, s, ws.id_sorted, ws.cnt_sorted, ws.scan_tmp, ws.sum4096, nsum, ws.rect_sorted, (uint32_t *)tile_items, n,
                            grid_x, D, id_shift, chunk, (1 << bits0) - 1, hist, acc, g.sb);
