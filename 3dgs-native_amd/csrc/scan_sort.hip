@@ -292,18 +292,29 @@ __device__ __forceinline__ void radix_hist_block(const ItemT *__restrict__ in, i
     __syncthreads();
     const int64_t base = (int64_t)block * CHUNK;
     // loads first, LDS atomics after: otherwise every round waits for its own load (RADIX_ITEMS serial round trips)
-    ItemT item[RADIX_ITEMS];
+    // (16-byte loads: a histogram does not care which thread counts which item; `in` and every chunk start are 16-byte aligned)
+    constexpr int VEC = 16 / (int)sizeof(ItemT);
+    static_assert(RADIX_ITEMS % VEC == 0, "whole 16-byte loads per thread");
+    struct alignas(16) Vec { ItemT v[VEC]; };
+    Vec item[RADIX_ITEMS / VEC];
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; ++r) {
-        const int64_t k = base + r * 256 + threadIdx.x;
-        item[r] = k < n ? in[k] : (ItemT)0;
+    for (int r = 0; r < RADIX_ITEMS / VEC; ++r) {
+        const int64_t k = base + (int64_t)(r * 256 + (int)threadIdx.x) * VEC;
+        if (k + VEC <= n) item[r] = *reinterpret_cast<const Vec *>(in + k);
+        else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) item[r].v[j] = k + j < n ? in[k + j] : (ItemT)0;
+        }
     }
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; ++r) {
-        const int64_t k = base + r * 256 + threadIdx.x;
-        bool take = k < n;
-        if constexpr (DEPTH) take = take && !(drop_culled && (uint32_t)(item[r] >> 32) == 0xFFFFFFFFu);
-        if (take) atomicAdd(&h[radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange)], 1);
+    for (int r = 0; r < RADIX_ITEMS / VEC; ++r) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int64_t k = base + (int64_t)(r * 256 + (int)threadIdx.x) * VEC + j;
+            bool take = k < n;
+            if constexpr (DEPTH) take = take && !(drop_culled && (uint32_t)(item[r].v[j] >> 32) == 0xFFFFFFFFu);
+            if (take) atomicAdd(&h[radix_digit<DEPTH, BITS>(item[r].v[j], shift, kmin, krange)], 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x < RADIX) {
