@@ -14,7 +14,8 @@ from collections import defaultdict
 STAGE_OF = [("preprocess_kernel", "preprocess"), ("blend_forward_kernel", "blend_fwd"), ("blend_backward_splat_kernel", "blend_bwd"),
             ("geom_backward_kernel", "geom_bwd"), ("expand_kernel", "expand"), ("ranges_kernel", "ranges"), ("scan_reduce_kernel<0>", "scan"),
             ("scan_final_kernel<0>", "scan"), ("scan_reduce_kernel<2>", "depth_scan"), ("scan_final_kernel<2>", "depth_scan"),
-            ("pack_records_kernel", "bwd_prep"), ("fillBufferAligned", "bwd_prep")]
+            ("pack_records_kernel", "bwd_prep"), ("fillBufferAligned", "bwd_prep"), ("expand_blocks_kernel", "expand"),
+            ("scan_ctl_hist_kernel", "scan"), ("depth_block_offsets_kernel", "depth_scan"), ("ranges_fixup_kernel", "tile_sort")]
 
 
 def short(name):
@@ -35,6 +36,14 @@ def read(path, counter):
     return tot, calls
 
 
+def radix_stage(kernel):
+    """radix_scatter_kernel<ITEMS, BITS, type, CARRY, FINAL, DEPTH, THREADS> / radix_hist_kernel<ITEMS, BITS, type, DEPTH>: the DEPTH
+    flag tells the N-item depth passes from the D-item tile passes (chunk sizes and thread counts changed in round 4)."""
+    args = [a.strip() for a in kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")] if "<" in kernel else []
+    flag = args[5] if kernel.startswith("radix_scatter") and len(args) > 5 else args[3] if kernel.startswith("radix_hist") and len(args) > 3 else ""
+    return "depth_sort" if flag in ("true", "1") else "tile_sort"
+
+
 def main():
     label, config, fetch_csv, write_csv, outdir = sys.argv[1:6]
     ft, fc = read(fetch_csv, "FETCH_SIZE")
@@ -49,8 +58,7 @@ def main():
         per_step = (2 * ft[k] + wt.get(k, 0.0)) * 1024 / steps
         st = next((s for pat, s in STAGE_OF if pat in k), None)
         if st is None and k.startswith("radix_"):
-            # 4096-item chunks (ITEMS=16) are the D-item tile passes, 1024-item chunks (ITEMS=4) the N-item depth passes
-            st = "tile_sort" if "<16," in k else "depth_sort"
+            st = radix_stage(k)
         if st:
             stage[st] += per_step
     with open(os.path.join(outdir, f"{label}_pmc_fetch_write_summary.csv"), "w") as f:
