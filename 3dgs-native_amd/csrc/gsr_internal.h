@@ -118,7 +118,9 @@ bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes
 #ifndef GSR_RADIX_SMALL_CHUNK
 #define GSR_RADIX_SMALL_CHUNK 2048
 #endif
+#ifndef GSR_RADIX_SMALL_N
 #define GSR_RADIX_SMALL_N (4 << 20)
+#endif
 static inline int gsr_radix_chunk(int64_t n) { return n <= GSR_RADIX_TINY_N ? GSR_RADIX_TINY_CHUNK : n <= GSR_RADIX_SMALL_N ? GSR_RADIX_SMALL_CHUNK : GSR_RADIX_CHUNK; }
 static inline int64_t gsr_radix_blocks(int64_t n) { const int c = gsr_radix_chunk(n); return (n + c - 1) / c; }
 // A pass's blocks are grouped into super-blocks of about sqrt(nb) blocks; its accumulators are 256 digit totals followed by
