@@ -258,6 +258,31 @@ def test_alignment_and_capacity_are_checked_before_any_hip_call(libpath):
         _lib.check(_lib.GSR_E_ALIGN)
 
 
+def test_packed_cameras_are_kept_by_the_bytes_of_their_inputs(cameras):
+    """_host.make_camera keeps the packed GsrCamera under the bytes of the arrays it was made from (numpy has no version counter):
+    the same values give the same struct back, a value written in place gives a new one, and either equals a fresh packing."""
+    import importlib
+    host = importlib.import_module(PKG_NAME + "._host")
+    cam = lego_camera(cameras, frame=2, width=64, height=48)
+    view, proj, pos = (np.array(cam[k], copy=True) for k in ("world_to_camera", "full_proj_matrix", "camera_center"))
+    bg = np.zeros(3, np.float32)
+    args = (view, proj, pos, bg, cam["tan_fovx"], cam["tan_fovy"], 64, 48)
+    a = host.make_camera(*args)
+    assert host.make_camera(*args) is a                                   # kept
+    assert host.make_camera(view.copy(), proj.copy(), pos.copy(), bg.copy(), *args[4:]) is a    # by value, not by identity
+    fresh = host._pack_camera(*args)
+    assert bytes(a) == bytes(fresh)
+    view[3, 0] += 0.25                                                    # the caller moves its camera in place
+    b = host.make_camera(*args)
+    assert b is not a and bytes(b) == bytes(host._pack_camera(*args)) and bytes(b) != bytes(fresh)
+    assert host.make_camera(view, proj, pos, bg, cam["tan_fovx"], cam["tan_fovy"], 64, 64) is not b      # another image size
+    assert host.make_camera(view.astype(np.float64), proj, pos, bg, *args[4:]) is not b and \
+        bytes(host.make_camera(view.astype(np.float64), proj, pos, bg, *args[4:])) == bytes(b)          # another dtype, same camera
+    lists = host.make_camera(view.tolist(), proj, pos, bg, *args[4:])       # not arrays: packed every time, same contents
+    assert lists is not b and bytes(lists) == bytes(b)
+    assert host.ptr(None) is None
+
+
 def test_arena_offsets_are_16_byte_aligned():
     d = sub("dist")
     for n in (0, 1, 2, 3, 5, 7, 1000, 100003):
