@@ -279,6 +279,7 @@ void read_tuning()
         if (const char *e = getenv("GSR_BWD_XCD")) gsr_bwd_xcd_map = atoi(e);
         if (const char *e = getenv("GSR_FWD_XCD")) gsr_fwd_xcd_map = atoi(e) != 0;
         if (const char *e = getenv("GSR_BWD_NO_ORDER")) gsr_bwd_no_order = atoi(e) != 0;
+        if (const char *e = getenv("GSR_NO_NARROWING")) gsr_no_narrowing = atoi(e) != 0;
         if (const char *e = getenv("GSR_FWD_NO_ORDER")) gsr_fwd_no_order = atoi(e) != 0;
     });
 }
@@ -488,11 +489,20 @@ int gsr_forward_render(const GsrScene *scene, const GsrCamera *camera, const Gsr
     mark(st, 6, s);
     // 4. stable partition by tile id
     void *tsrc = bw.tile_a, *tdst = bw.tile_b;
+    // Two passes over 64-bit items whose remaining tile bits + id bits fit a word after the first one (1080p with 5 M Gaussians:
+    // 6 + 23): the first pass writes 32-bit items and the second recovers the first digit from the item's position
+    // (scan_sort.hip ScatterFinal) -- 4 instead of 8 bytes per item through the second histogram and the final scatter.
+    const int bits0 = pass_bits(0, 0);
+    const bool narrowing = !narrow && npass == 2 && (tb - bits0) + id_bits <= 32 && !gsr_no_narrowing;
     for (int pass = 0, shift = 0; pass < npass; ++pass) {
         const int bits = pass_bits(pass, shift);
         const bool hist_ready = pass == 0 && !by_gaussian;
         if (pass + 1 < npass) {
-            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, bw.acc[(pass + 1) & 1], s, hist_ready));
+            HIP_TRY(gsr_launch_radix_pass(tsrc, tdst, bw.hist, bw.acc[pass & 1], D, id_shift + shift, bits, item_bytes, bw.acc[(pass + 1) & 1], s, hist_ready,
+                                          narrowing ? id_bits : 0, narrowing ? bw.acc[pass & 1] : nullptr));
+        } else if (narrowing) {
+            HIP_TRY(gsr_launch_radix_final_pass(tsrc, bw.hist, bw.acc[pass & 1], D, id_bits, bits, 4, id_bits, binning->point_list, binning->ranges, bw.edge, s,
+                                                false, bw.acc[(pass + 1) & 1], bits0));
         } else {
             // 5. the last pass writes point_list and the tile ranges itself (reference forward.py:806-824, :561-586) instead of
             //    sorted items that a further kernel would re-read

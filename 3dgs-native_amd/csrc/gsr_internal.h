@@ -140,13 +140,16 @@ static inline size_t gsr_radix_acc_ints(int64_t n)
 }
 hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist /*[nb][radix]*/, int32_t *acc /* gsr_radix_acc_ints(n), zero */,
                                  int64_t n, int shift, int bits, int item_bytes, int32_t *zero_acc /* next pass's, or NULL */, hipStream_t s,
-                                 bool hist_ready = false /* hist and acc were filled by gsr_launch_expand_blocks */);
+                                 bool hist_ready = false /* hist and acc were filled by gsr_launch_expand_blocks */,
+                                 int narrow_id_bits = 0 /* 64-bit items only: > 0 = write 32-bit items (tile >> bits) << narrow_id_bits | id ... */,
+                                 int32_t *totals_out = nullptr /* ... and leave the digit totals here for the final pass (scan_sort.hip ScatterFinal) */);
 
 // Last pass of the tile partition: writes point_list and ranges instead of the sorted items (scan_sort.hip, ScatterFinal).
 // `edge`: 3 * 256 * (gsr_radix_blocks(n) + 1) int32 of scratch.
 hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
                                        int id_shift, int32_t *point_list, int32_t *ranges /* pre-zeroed */, int32_t *edge, hipStream_t s,
-                                       bool hist_ready = false);
+                                       bool hist_ready = false, const int32_t *low_totals = nullptr /* narrowed items: the first pass's digit totals */,
+                                       int low_bits = 0 /* ... and digit width */);
 
 // Tile items are (tile << id_shift | gaussian id): uint64 with id_shift = 32, or uint32 when tile bits + id bits <= 32.
 hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, const TileRect *rect, void *tile_items,
@@ -169,6 +172,7 @@ hipError_t gsr_launch_expand(const uint32_t *id_sorted, const int32_t *doff, con
 // every frame from whatever fwd_cost holds -- garbage in a fresh workspace gives some permutation, never a wrong one).  Execution
 // order only: every tile computes what it always did.  Not for images of more than GSR_FO_MAX_TILES tiles (many rounds, no tail).
 extern int gsr_fwd_no_order; // GSR_FWD_NO_ORDER: plain row-major dispatch (A/B)
+extern int gsr_no_narrowing; // GSR_NO_NARROWING: the second tile pass keeps 64-bit items where the first could narrow them (A/B, tests)
 hipError_t gsr_launch_depth_block_offsets(const GeomWs &ws, int64_t n, int32_t *ranges, int ranges_n, int32_t *zero_acc, int zero_n, int32_t *zero_b,
                                           int zero_b_n, int bo_flag, hipStream_t s);
 hipError_t gsr_launch_expand_blocks(const GeomWs &ws, void *tile_items, int64_t n, int grid_x, int64_t D, int id_shift, int item_bytes, int bits0,

@@ -451,11 +451,19 @@ struct ScatterFinal {
     int32_t *edge_first;  // [RADIX * nb] tile of the run's first item, -1 for an empty run
     int32_t *edge_last;   // [RADIX * nb] tile of the run's last item
     int32_t *edge_pos;    // [RADIX * nb] output position of the run's first item
-    int32_t *totals;      // [RADIX] items per digit, for ranges_fixup_kernel (written by block 0)
+    int32_t *totals;      // [RADIX] items per digit, for ranges_fixup_kernel (written by block 0; a non-final pass writes them too when asked)
     int id_shift;
+    // Narrowed items (two-pass partitions whose tile + id bits exceed 32, e.g. 1080p with 5 M Gaussians: 13 + 23).  The first pass
+    // reads the 64-bit items (tile << 32 | id) and WRITES 32-bit ones, (tile >> bits0) << narrow_id_bits | id: the digit it has
+    // just sorted by is implied by the item's position in its output (that output is grouped by it), so the second pass -- its
+    // histogram and its scatter, the FINAL one -- moves 4 bytes per item instead of 8 and recovers the digit from the first
+    // pass's digit totals (low_totals, low_bits): a search of <= 256 segment starts per item.
+    int narrow_id_bits;          // non-final pass: > 0 = write 32-bit items with the id in this many low bits
+    const int32_t *low_totals;   // FINAL: the first pass's items per digit ...
+    int low_bits;                // ... and its digit width (0: the items hold the whole tile id)
 };
 
-template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false, int THREADS = 256>
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false, int THREADS = 256, bool LOWREC = false>
 __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ acc,
                                                             int64_t n, int shift, int nb, int sb, bool prefixed, int32_t *__restrict__ zero_acc,
@@ -474,6 +482,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
     int *const s_dstart = s_total;                 // first LDS slot of each digit
     int *const s_gbase = s_before;                 // global position of the block's first item of each digit
     __shared__ int s_dcnt[FINAL ? RADIX : 1];      // FINAL: items of each digit in this block
+    __shared__ uint8_t s_low[LOWREC ? CHUNK : 1];  // LOWREC (FINAL with narrowed items): each item's first-pass digit, reordered with it
+    __shared__ int s_seg[LOWREC ? 257 : 1];        // ... and where each first-pass digit's segment of the input starts
     __shared__ int s_tmp[NW];
     __shared__ int s_valid_n;
 
@@ -515,6 +525,14 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
         if (block_base >= n) return;
     }
     __syncthreads();
+    if constexpr (LOWREC) { // exclusive prefix of the first pass's digit totals = the segments of this pass's input
+        int tot;
+        const int v = (tid < (1 << fin.low_bits)) ? fin.low_totals[tid] : 0;
+        const int inc = block_incl_scan_nw<NW>(tid < 256 ? v : 0, s_tmp, &tot);
+        if (tid < 256) s_seg[tid + 1] = inc;
+        if (tid == 0) s_seg[0] = 0;
+        __syncthreads();
+    }
 
     // items of each digit in earlier blocks = whole super-blocks (accumulators) + the earlier blocks of the own super-block
     // (block histograms): about 2 sqrt(nb) terms per digit, spread over the block's 256 / RADIX threads per digit, coalesced
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
     ItemT item[RADIX_ITEMS];
     unsigned long long rc[CARRY ? RADIX_ITEMS : 1]; // raw TileRect bits
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
+    uint8_t low[LOWREC ? RADIX_ITEMS : 1]; // LOWREC: the item's first-pass digit
     bool valid_bits[RADIX_ITEMS];
     // every load is issued before the ranking starts (the ranking's branches would otherwise pin each load to its own
     // round: RADIX_ITEMS serial memory round trips per wave)
@@ -591,6 +610,13 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
         bool valid = k < n;
         if constexpr (DEPTH) valid = valid && !(drop_culled && (uint32_t)(item[r] >> 32) == 0xFFFFFFFFu);
         valid_bits[r] = valid;
+        if constexpr (LOWREC) {
+            int p = 0; // the last segment that starts at or before input position k (empty segments share their successor's start)
+#pragma unroll
+            for (int step = 128; step >= 1; step >>= 1)
+                if (s_seg[p + step] <= (int)min(k, n - 1)) p += step;
+            low[r] = (uint8_t)p;
+        }
         const int d = radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange);
         // lanes holding the same digit ("match any"): a lane differs from me in bit b where ballot(bit b) XOR (my bit b
         // replicated) is set; OR over the bits, complement.  Written on 32-bit halves with the replicated bit as one signed
@@ -639,6 +665,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
         if (own) {
             s_dstart[d] = inc - run;
             s_gbase[d] = tinc - td + before;
+            if constexpr (!FINAL && sizeof(ItemT) == 8 && !DEPTH) {
+                if (fin.totals && blockIdx.x == 0) fin.totals[d] = td; // (a narrowing pass: the final pass finds each item's digit of THIS pass from these)
+            }
             if constexpr (FINAL) {
                 if (blockIdx.x == 0) fin.totals[d] = td;
                 s_dcnt[d] = run;
@@ -655,6 +684,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
             const int d = radix_digit<DEPTH, BITS>(item[r], shift, kmin, krange);
             const int slot = s_dstart[d] + s_wcnt[w][d] + rank[r];
             s_items[slot] = item[r];
+            if constexpr (LOWREC) s_low[slot] = low[r];
             if constexpr (CARRY) s_rect[slot] = rc[r];
         }
     }
@@ -670,12 +700,14 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
             const int d = radix_digit<DEPTH, BITS>(it, shift, kmin, krange);
             const int64_t pos = (int64_t)s_gbase[d] + (slot - s_dstart[d]);
             if constexpr (FINAL) {
-                const uint32_t tile = (uint32_t)(it >> fin.id_shift);
+                uint32_t tile = (uint32_t)(it >> fin.id_shift);
+                if constexpr (LOWREC) tile = (tile << fin.low_bits) | (uint32_t)s_low[slot];
                 fin.point_list[pos] = (int32_t)(uint32_t)(it & (((ItemT)1 << fin.id_shift) - 1));
                 const int rel = slot - s_dstart[d];
                 const size_t e = (size_t)d * nb + blockIdx.x;
                 if (rel > 0) {
-                    const uint32_t prev = (uint32_t)(s_items[slot - 1] >> fin.id_shift);
+                    uint32_t prev = (uint32_t)(s_items[slot - 1] >> fin.id_shift);
+                    if constexpr (LOWREC) prev = (prev << fin.low_bits) | (uint32_t)s_low[slot - 1];
                     if (prev != tile) {
                         fin.ranges[2 * prev + 1] = (int32_t)pos;
                         fin.ranges[2 * tile] = (int32_t)pos;
@@ -688,7 +720,14 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
             } else if constexpr (CARRY) {
                 carry.id_sorted[pos] = (uint32_t)it; // the last depth pass: ids, rectangles and counts leave, not the items
             } else {
-                out[pos] = it;
+                bool narrowed = false;
+                if constexpr (sizeof(ItemT) == 8 && !DEPTH) { // (uniform) the digit just sorted by leaves the item: see ScatterFinal
+                    if (fin.narrow_id_bits) {
+                        reinterpret_cast<uint32_t *>(out)[pos] = (uint32_t)(((it >> (shift + BITS)) << fin.narrow_id_bits) | (it & (((ItemT)1 << fin.narrow_id_bits) - 1)));
+                        narrowed = true;
+                    }
+                }
+                if (!narrowed) out[pos] = it;
             }
             if constexpr (CARRY) {
                 const unsigned long long q = s_rect[slot]; // TileRect {x0, y0, x1, y1}, 16 bits each, little endian
@@ -1201,7 +1240,7 @@ static PassGeom pass_geom(int64_t n)
     return g;
 }
 
-template <int BITS, typename ItemT, bool CARRY, bool FINAL, bool DEPTH = false>
+template <int BITS, typename ItemT, bool CARRY, bool FINAL, bool DEPTH = false, bool LOWREC = false>
 static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int32_t *zero_acc, int zero_n,
                               const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s, const DepthPass &dp = DepthPass{}, bool hist_ready = false)
 {
@@ -1218,13 +1257,13 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
     }
     if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
     if (g.tier == 0) {
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_TINY_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH, 256>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n, shift,
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_TINY_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH, 256, LOWREC>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n, shift,
                            g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else if (g.tier == 1) {
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / GSR_RADIX_SMALL_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_SMALL_WG>), dim3(g.nb), dim3(GSR_RADIX_SMALL_WG),
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / GSR_RADIX_SMALL_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_SMALL_WG, LOWREC>), dim3(g.nb), dim3(GSR_RADIX_SMALL_WG),
                            0, s, in, out, hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / GSR_RADIX_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_WG>), dim3(g.nb), dim3(GSR_RADIX_WG), 0, s, in, out,
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / GSR_RADIX_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_WG, LOWREC>), dim3(g.nb), dim3(GSR_RADIX_WG), 0, s, in, out,
                            hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
     if constexpr (FINAL)
@@ -1238,6 +1277,19 @@ static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int
 {
     const ScatterCarry nc{};
     const DepthPass nd{};
+    if constexpr (FINAL && sizeof(ItemT) == 4) {
+        if (fin.low_bits) { // narrowed items: the kernel that also recovers the first pass's digit (ScatterFinal)
+            switch (bits) {
+            case 4: radix_pass_launch<4, ItemT, false, true, false, true>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+            case 5: radix_pass_launch<5, ItemT, false, true, false, true>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+            case 6: radix_pass_launch<6, ItemT, false, true, false, true>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+            case 7: radix_pass_launch<7, ItemT, false, true, false, true>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+            case 8: radix_pass_launch<8, ItemT, false, true, false, true>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (bits) {
     case 4: radix_pass_launch<4, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
     case 5: radix_pass_launch<5, ItemT, false, FINAL>(in, out, hist, acc, n, shift, zero_acc, zero_n, nc, fin, s, nd, hist_ready); break;
@@ -1255,23 +1307,29 @@ static hipError_t radix_pass_any(const ItemT *in, ItemT *out, int32_t *hist, int
 // `acc`: this pass's accumulators (gsr_radix_acc_ints(n) ints, zero when the pass's first kernel runs); `zero_acc`: the
 // accumulators of the NEXT pass over the same n, cleared by this pass's scatter (or NULL).
 hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
-                                 int32_t *zero_acc, hipStream_t s, bool hist_ready)
+                                 int32_t *zero_acc, hipStream_t s, bool hist_ready, int narrow_id_bits, int32_t *totals_out)
 {
     if (n <= 0) return hipSuccess;
     const int zero_n = zero_acc ? (int)gsr_radix_acc_ints(n) : 0;
+    ScatterFinal opt{};
+    opt.narrow_id_bits = item_bytes == 8 ? narrow_id_bits : 0; // 64-bit items in, 32-bit items out (see ScatterFinal)
+    opt.totals = opt.narrow_id_bits ? totals_out : nullptr;
     if (item_bytes == 4)
-        return radix_pass_any<uint32_t, false>((const uint32_t *)in, (uint32_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s, hist_ready);
-    return radix_pass_any<uint64_t, false>((const uint64_t *)in, (uint64_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, ScatterFinal{}, s, hist_ready);
+        return radix_pass_any<uint32_t, false>((const uint32_t *)in, (uint32_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, opt, s, hist_ready);
+    return radix_pass_any<uint64_t, false>((const uint64_t *)in, (uint64_t *)out, hist, acc, n, shift, bits, zero_acc, zero_n, opt, s, hist_ready);
 }
+
+int gsr_no_narrowing = 0; // GSR_NO_NARROWING (gsr_internal.h)
 
 // The LAST pass of the tile partition: histogram, then a scatter that writes point_list and the in-sight range boundaries
 // directly (ScatterFinal), and the edge fix-up.  `edge` holds 3 * (1 << bits) * nb int32 (gsr_radix_blocks(n) = nb).
 hipError_t gsr_launch_radix_final_pass(const void *in, int32_t *hist, int32_t *acc, int64_t n, int shift, int bits, int item_bytes,
-                                       int id_shift, int32_t *point_list, int32_t *ranges, int32_t *edge, hipStream_t s, bool hist_ready)
+                                       int id_shift, int32_t *point_list, int32_t *ranges, int32_t *edge, hipStream_t s, bool hist_ready,
+                                       const int32_t *low_totals, int low_bits)
 {
     if (n <= 0) return hipSuccess;
     const size_t per = ((size_t)1 << bits) * (size_t)gsr_radix_blocks(n);
-    const ScatterFinal fin{point_list, ranges, edge, edge + per, edge + 2 * per, acc, id_shift};
+    const ScatterFinal fin{point_list, ranges, edge, edge + per, edge + 2 * per, acc, id_shift, 0, low_totals, low_totals ? low_bits : 0};
     if (item_bytes == 4) return radix_pass_any<uint32_t, true>((const uint32_t *)in, (uint32_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s, hist_ready);
     return radix_pass_any<uint64_t, true>((const uint64_t *)in, (uint64_t *)nullptr, hist, acc, n, shift, bits, nullptr, 0, fin, s, hist_ready);
 }

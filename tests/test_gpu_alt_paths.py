@@ -51,6 +51,19 @@ def test_parity_with_each_backward_block_size(px):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("narrowing", [True, False])
+def test_wide_tile_items_over_two_passes(narrowing):
+    """Tile id bits + Gaussian id bits beyond 32 (1080p with 5 M Gaussians: 13 + 23) make the tile partition run on 64-bit items; with
+    two passes the first one then writes 32-bit items and the last recovers the first digit from each item's position
+    (GSR_NO_NARROWING=1: it keeps 64-bit items, the path of rounds 1-3).  GSR_DEBUG bit 5 forces the wide items at any size, the
+    unusual image shapes (more than 256 tiles: two passes) supply the sizes; forward and backward against the oracle."""
+    env = dict(os.environ, GSR_DEBUG="32", GSR_NO_NARROWING="0" if narrowing else "1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_odd_sizes.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_two_training_steps_with_the_forward_xcd_map():
     """GSR_FWD_XCD=1 (neighbouring tiles of the forward blend on one XCD) cannot host the spare workgroups that clear the backward's
     accumulators; the forward must then clear them another way, or the SECOND step's gradients would carry the first step's sums
