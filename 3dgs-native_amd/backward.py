@@ -116,7 +116,19 @@ def backward(background, means3D, dL_dpixels, opacity=None, shs=None, scales=Non
     else:
         m2d = con = col = None
     cl = _host.to_dev(clamped, f32, dev, (-1, 3))
-    c3 = _host.to_dev(cov3Ds, f32, dev, (-1, 6))
+    # Sigma3D is recomputed inside the kernel instead of read back (24 bytes per Gaussian) when `cov3Ds` is the forward's own tensor,
+    # unwritten, made from these very scales / rotations (unwritten too) with this scale_modifier (forward.py; gsr.h GsrGeom.cov3D)
+    c3 = None
+    sig_tag = getattr(cov3Ds, "_gsr_sigma_of", None)
+    if sig_tag is not None:
+        sc_ref, rot_ref, sc_ver, rot_ver, smod, c_ver = sig_tag
+        recompute = (sc_ref() is scales and rot_ref() is rotations and _host.version_of(scales) == sc_ver and _host.version_of(rotations) == rot_ver
+                     and smod == float(scale_modifier) and cov3Ds._version == c_ver and cov3Ds.device == dev and cov3Ds.shape[0] == N)
+    else:
+        recompute = False
+    backward.last_call_recomputed_sigma3d = recompute     # for tests and debugging
+    if not recompute:
+        c3 = _host.to_dev(cov3Ds, f32, dev, (-1, 6))
     ranges = _host.to_dev(ranges, i32, dev, (-1, 2))
     final_Ts = _host.to_dev(final_Ts, f32, dev, (H, W))
     n_contrib = _host.to_dev(n_contrib, i32, dev, (H, W))

@@ -535,7 +535,7 @@ static int backward_blend_impl(const GsrScene *scene, const GsrCamera *camera, c
                                const GsrImage *image, const float *dL_dpixels, float *payload, void *ws, size_t ws_bytes, hipStream_t s, int st)
 {
     const int64_t N = scene->N;
-    if (!geom || !geom->radii || !geom->cov3D || !geom->clamped_state) return GSR_E_NULL;
+    if (!geom || !geom->radii || !geom->clamped_state) return GSR_E_NULL; // (cov3D may be NULL: gsr.h GsrGeom)
     if (!geom->blend_records && (!geom->xy || !geom->rgb || !geom->conic_opacity)) return GSR_E_NULL; // the records, or what they are rebuilt from
     if (!binning || !image || !dL_dpixels) return GSR_E_NULL;
     if (!geom_aligned(geom) || !gsr_aligned16(ws) || !gsr_aligned16(binning->point_list) || !gsr_aligned16(binning->ranges) ||
@@ -572,7 +572,7 @@ static int backward_geom_impl(const GsrScene *scene, const GsrCamera *camera, co
     // dL_dshs and dL_drgb may both be NULL here: the payload was taken from the blend half and the SH gradient is rebuilt later
     // (dL_dcolor / dL_dmean2D / dL_dconic may each be NULL: they are columns of the accumulator records in `ws`, gsr.h GsrGrads)
     if (!grads || !grads->dL_dmean3D || !grads->dL_dscale || !grads->dL_drot || !grads->dL_dopacity) return GSR_E_NULL;
-    if (!geom || !geom->radii || !geom->cov3D || !geom->clamped_state) return GSR_E_NULL;
+    if (!geom || !geom->radii || !geom->clamped_state) return GSR_E_NULL; // cov3D NULL: recomputed from scales / rotations (gsr.h GsrGeom)
     if (!geom_aligned(geom) || !grads_aligned(grads) || !gsr_aligned16(ws)) return GSR_E_ALIGN;
     if (!ws || ws_bytes < gsr_backward_workspace_bytes(N, 0, camera->W, camera->H)) return GSR_E_WORKSPACE;
     const CamK cam = make_cam(camera);

@@ -17,6 +17,7 @@
 // its scale_modifier down (backward.py:1155-1182; default 1.0 at :805), so the cov3d part runs with 1.0.
 #include "gsr_internal.h"
 #include "sh_stage.h"
+#include "sigma3d.h"
 
 namespace {
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     const float *__restrict__ cov3Ds, const float *__restrict__ clamped_state, const GradRec *__restrict__ acc,
     float *__restrict__ dL_dmean3D, float *__restrict__ dL_dscale, float *__restrict__ dL_drot, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dshs, float *__restrict__ dL_dcolor, float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic,
-    float *__restrict__ dL_drgb, const float *__restrict__ sh_dir_grad)
+    float *__restrict__ dL_drgb, const float *__restrict__ sh_dir_grad, float scale_mod)
 {
     // SH rows (input coefficients, then in place the output gradients) live in LDS; moved cooperatively
     __shared__ float4 s_rows[4 * SH_WAVE_F4];
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     int sh_written = 0; // number of leading SH coefficients whose gradient was written into the LDS row
     float o_rgb[3] = {0.f, 0.f, 0.f}; // dL_dcolor * (1 - clamped) where the SH backward runs, else 0 (optional output)
     bool vis = false;
+    float sv[3] = {0.f, 0.f, 0.f};
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in_range) {
 
     const float4 *ap = reinterpret_cast<const float4 *>(acc + idx);
@@ -124,12 +127,21 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
     vis = my_radius > 0;
     if (vis) {
         mean[0] = gsr_ld1<GSR_NT_INPUTS != 0>(means + 3 * idx); mean[1] = gsr_ld1<GSR_NT_INPUTS != 0>(means + 3 * idx + 1); mean[2] = gsr_ld1<GSR_NT_INPUTS != 0>(means + 3 * idx + 2);
+        // (scale and quaternion: the cov3d backward at the end needs them, and so does Sigma3D when it is recomputed)
+        sv[0] = gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx); sv[1] = gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx + 1); sv[2] = gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx + 2);
+        q = gsr_ld4<GSR_NT_INPUTS != 0>(reinterpret_cast<const float4 *>(rots + 4 * idx));
         // ---------------- cov2d backward (backward.py:259-435) ----------------
         {
             float c3[6];
+            if (cov3Ds) { // (uniform)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                c3[2 * k] = gsr_ld1<GSR_NT_INPUTS != 0>(cov3Ds + 6 * idx + 2 * k); c3[2 * k + 1] = gsr_ld1<GSR_NT_INPUTS != 0>(cov3Ds + 6 * idx + 2 * k + 1);
+                for (int k = 0; k < 3; ++k) {
+                    c3[2 * k] = gsr_ld1<GSR_NT_INPUTS != 0>(cov3Ds + 6 * idx + 2 * k); c3[2 * k + 1] = gsr_ld1<GSR_NT_INPUTS != 0>(cov3Ds + 6 * idx + 2 * k + 1);
+                }
+            } else {
+                // the caller vouches that GsrGeom.cov3D would be the forward's own output for these scales / rotations / scale
+                // modifier: the same instructions give the same bits (sigma3d.h) and 24 bytes per Gaussian are not read
+                gsr_sigma3d(scale_mod * sv[0], scale_mod * sv[1], scale_mod * sv[2], q, c3);
             }
             float t[4];
 #pragma unroll
@@ -294,8 +306,6 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(
         // ---------------- cov3d backward (backward.py:439-556), scale_modifier = 1.0 (Q16) ----------------
         {
             const float scale_modifier = 1.0f;
-            const float sv[3] = {gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx), gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx + 1), gsr_ld1<GSR_NT_INPUTS != 0>(scales + 3 * idx + 2)};
-            const float4 q = gsr_ld4<GSR_NT_INPUTS != 0>(reinterpret_cast<const float4 *>(rots + 4 * idx));
             const float r = q.w, x = q.x, y = q.y, z = q.z;
             const M33 R = {{{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
                             {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
@@ -411,7 +421,7 @@ hipError_t gsr_launch_geom_backward(const GsrScene &sc, const CamK &cam, const G
     hipLaunchKernelGGL(geom_backward_kernel<DG>, dim3((unsigned)gsr_div_up(sc.N, 256)), dim3(256), 0, s, sc.N, sc.means, sc.scales, \
                        sc.rotations, sc.sh, sc.sh_degree, cam, h_x, h_y, g.radii, g.cov3D, g.clamped_state, acc, gr.dL_dmean3D,  \
                        gr.dL_dscale, gr.dL_drot, gr.dL_dopacity, gr.dL_dshs, gr.dL_dcolor, gr.dL_dmean2D, gr.dL_dconic, gr.dL_drgb, \
-                       g.sh_dir_grad)
+                       g.sh_dir_grad, sc.scale_modifier)
     if (g.sh_dir_grad) GEOM_BWD(true);
     else GEOM_BWD(false);
 #undef GEOM_BWD

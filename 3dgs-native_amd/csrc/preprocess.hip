@@ -13,6 +13,7 @@
 #include "gsr_internal.h"
 #include "sh_stage.h"
 #include "fwd_order.h"
+#include "sigma3d.h"
 
 namespace {
 
@@ -121,26 +122,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         float opacity_i = gsr_ld1<NTI>(opac + i);
         asm volatile("" : "+v"(sc_x), "+v"(sc_y), "+v"(sc_z), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(opacity_i)); // not to be sunk back
         const float sx = scale_mod * sc_x, sy = scale_mod * sc_y, sz = scale_mod * sc_z;
-        M33 R;
-        {
-            const float cs = 2.0f * q.w * q.w - 1.0f;
-            const float qv[3] = {q.x, q.y, q.z};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v[3] = {c == 0 ? 1.0f : 0.0f, c == 1 ? 1.0f : 0.0f, c == 2 ? 1.0f : 0.0f};
-                const float cr[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
-                float d = qv[0] * v[0];
-                d += qv[1] * v[1];
-                d += qv[2] * v[2];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) R.m[r][c] = v[r] * cs + cr[r] * q.w * 2.0f + qv[r] * d * 2.0f;
-            }
-        }
-        const M33 S = {{{sx, 0.0f, 0.0f}, {0.0f, sy, 0.0f}, {0.0f, 0.0f, sz}}};
-        const M33 M = mul33(R, S);
-        const M33 sig = mul33(M, tr33(M));
-        o_cov[0] = sig.m[0][0]; o_cov[1] = sig.m[0][1]; o_cov[2] = sig.m[0][2];
-        o_cov[3] = sig.m[1][1]; o_cov[4] = sig.m[1][2]; o_cov[5] = sig.m[2][2];
+        gsr_sigma3d(sx, sy, sz, q, o_cov); // (sigma3d.h: shared with the geometry backward, which may recompute it)
 
         // EWA projection.  T = J * W with W = view[0:3,0:3] as stored (quirk Q1: forward convention).
         float t0, t1;

@@ -21,6 +21,7 @@ PRECLEAR_BACKWARD = not bool(int(os.environ.get("GSR_NO_PRECLEAR", "0")))
 _backward_seen = False          # set by backward.backward()
 _NO_SH_DIR = bool(int(os.environ.get("GSR_NO_SH_DIR", "0")))
 _NO_RECORD_VIEWS = bool(int(os.environ.get("GSR_NO_RECORD_VIEWS", "0")))
+_NO_COV_RECOMPUTE = bool(int(os.environ.get("GSR_NO_COV_RECOMPUTE", "0")))   # A/B switch: backward() always reads cov3Ds back
 _NO_BLOCK_ORDER = bool(int(os.environ.get("GSR_NO_BLOCK_ORDER", "0")))     # A/B switch: the forward does not file the backward's blocks by cost   # A/B switch: packed xy / conic_opacity / colors arrays beside the records   # A/B switch: backward reads the SH rows itself (same results)
 
 
@@ -113,6 +114,10 @@ def render_gaussians(background, means3D, colors=None, opacity=None, scales=None
             # writers, Adam and the opacity reset, bump them too: _host.written_in_place)
             clamped_state._gsr_sh_dir = (sh_dir, weakref.ref(sh), weakref.ref(means3D), tuple(cam.campos), int(degree),
                                          sh._version, means3D._version)
+        if in_place(scales, sc) and in_place(rotations, rot) and not _NO_COV_RECOMPUTE:
+            # backward() need not read cov3Ds back when it is handed this very tensor, unwritten, with these very scales / rotations
+            # (unwritten too) and the same scale_modifier: the kernel recomputes Sigma3D with the forward's instructions (gsr.h GsrGeom.cov3D)
+            cov3Ds._gsr_sigma_of = (weakref.ref(scales), weakref.ref(rotations), scales._version, rotations._version, float(scale_modifier), cov3Ds._version)
         owners = {"ranges": ranges, "n_contrib": n_contrib, "final_Ts": final_Ts, "means2D": xy, "conic_opacity": conic_opacity}
         point_list._gsr_block_masks = (block_masks, {k: (weakref.ref(v), v._version) for k, v in owners.items()}, block_order)
         if bwd_ws is not None:      # "a backward workspace with clean accumulators": the first backward() handed this point_list takes it

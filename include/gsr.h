@@ -93,7 +93,9 @@ typedef struct GsrGeom {
     int32_t *point_offsets; /* [N] inclusive scan of tiles_touched (utils/wp_utils.py:47-60) */
     float *xy;              /* [N*2] */
     float *depths;          /* [N] */
-    float *cov3D;           /* [N*6] */
+    float *cov3D;           /* [N*6].  gsr_backward: may be NULL when it would be the forward's own output for this scene's scales,
+                               rotations and scale_modifier -- the kernel then recomputes it (the same instructions, the same bits)
+                               instead of reading 24 bytes per Gaussian; a caller with its own Sigma3D passes it as before */
     float *rgb;             /* [N*3] */
     float *conic_opacity;   /* [N*4] */
     float *clamped_state;   /* [N*3] */

@@ -420,6 +420,76 @@ def test_sh_direction_sums_handed_from_forward_to_backward(oracle, cameras, scen
                 np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()), err_msg=f"{swap} {k}")
 
 
+def test_sigma3d_recomputed_only_for_the_forwards_own_array(oracle, cameras, scenes):
+    """backward() does not read cov3Ds back when it is the forward's own tensor, unwritten, for the very scales / rotations tensors
+    (unwritten too) and scale_modifier of that forward: the kernel recomputes Sigma3D with the forward's instructions (sigma3d.h: one
+    definition for both kernels).  Same gradients as the path that reads the array; any other cov3Ds -- a copy, a written one, one behind written scales -- is read,
+    as the reference reads it (backward.py:975-980)."""
+    import torch
+    gsr = pkg()
+    bwd = __import__("importlib").import_module(gsr.__name__ + ".backward").backward
+    W, H = 208, 160
+    sc = scenes.synthetic_scene(6000, 0.05, 0.6, 77)
+    cam = lego_camera(cameras, frame=3, width=W, height=H)
+    kw = render_kwargs(sc, cam, width=W, height=H)
+    kw["scale_modifier"] = 1.3
+    dev = {k_kw: torch.as_tensor(sc[k_np]).cuda() for k_np, k_kw in
+           [("means", "means3D"), ("opacities", "opacity"), ("scales", "scales"), ("rotations", "rotations"), ("shs", "sh")]}
+    kw.update(dev)
+    dpix = _pixel_grad(H, W)
+    buf = gsr.render_gaussians(**kw)[2]
+    scene_t = {"means": dev["means3D"], "opacities": dev["opacity"], "shs": dev["sh"], "scales": dev["scales"], "rotations": dev["rotations"]}
+    bkw = backward_kwargs(scene_t, cam, kw, buf, dpix)
+    g1 = gsr.backward(**bkw)
+    assert bwd.last_call_recomputed_sigma3d
+    bkw_copy = dict(bkw, cov3Ds=buf["cov3Ds"].clone())                       # not the forward's tensor: read
+    g2 = gsr.backward(**bkw_copy)
+    assert not bwd.last_call_recomputed_sigma3d
+    for k in ("dL_dmean3D", "dL_dscale", "dL_drot"):       # the same Sigma3D either way: what differs is the float-atomic order of two blend runs
+        assert float((g1[k] - g2[k]).abs().max()) <= 2e-5 * float(g2[k].abs().max()), k
+    # ... and bit for bit: the per-Gaussian half alone (gsr_backward_geom) over g1's accumulators, once handed the array, once NULL
+    import ctypes as C
+    pk = gsr.__name__
+    _lib, _host = (__import__("importlib").import_module(pk + "." + m) for m in ("_lib", "_host"))
+    L, N = _lib.lib(), dev["means3D"].shape[0]
+    # the call's backward workspace: dL_dcolor is a view of its accumulator records, which start gsr_backward_accumulators_offset(N) in
+    acc_flat = g1["dL_dcolor"]._base
+    assert acc_flat is not None and acc_flat.numel() == 16 * N
+    ws_ptr = acc_flat.data_ptr() - int(L.gsr_backward_accumulators_offset(N))
+    ws_bytes = int(L.gsr_backward_workspace_bytes(N, int(buf["point_list"].shape[0]), W, H))
+    scene_c = _lib.GsrScene(N, _host.ptr(dev["means3D"]), _host.ptr(dev["scales"]), _host.ptr(dev["rotations"]), _host.ptr(dev["opacity"]),
+                            _host.ptr(dev["sh"].view(-1, 3)), 3, 1.3, 1)
+    cam_c = _host.make_camera(kw["viewmatrix"], kw["projmatrix"], kw["campos"], kw["background"], kw["tan_fovx"], kw["tan_fovy"], W, H)
+    outs = []
+    for cov in (buf["cov3Ds"], None):
+        geom_c = _lib.GsrGeom(_host.ptr(buf["radii"]), None, None, None, None, _host.ptr(cov), None, None, _host.ptr(buf["clamped_state"]), None, None)
+        o = [torch.empty(n, dtype=torch.float32, device="cuda") for n in (3 * N, 3 * N, 4 * N, N, 48 * N)]
+        grads_c = _lib.GsrGrads(*[_host.ptr(t) for t in o], None, None, None, None)
+        _lib.check(L.gsr_backward_geom(C.byref(scene_c), C.byref(cam_c), C.byref(geom_c), C.byref(grads_c), ws_ptr, ws_bytes, _host.raw_stream(acc_flat.device)))
+        outs.append(o)
+    torch.cuda.synchronize()
+    for a_, b_, name in zip(outs[0], outs[1], ("dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dshs")):
+        assert torch.equal(a_, b_), name
+    assert float(outs[0][1].abs().max()) > 0.0
+    ref_kw = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+    ref = oracle.render_gaussians(**ref_kw)
+    rb = backward_kwargs(sc, cam, ref_kw, ref[2], dpix)
+    parity.compare_backward(g1, oracle.backward(**rb), None)
+    # scales written in place after the forward: the array (made from the OLD scales) is read, as the reference would
+    with torch.no_grad():
+        dev["scales"].mul_(1.05)
+    g3 = gsr.backward(**bkw)
+    assert not bwd.last_call_recomputed_sigma3d
+    sc2 = dict(sc, scales=dev["scales"].cpu().numpy())
+    rb2 = backward_kwargs(sc2, cam, ref_kw, ref[2], dpix)                      # new scales, the old forward's buffers
+    parity.compare_backward(g3, oracle.backward(**rb2), None)
+    # another scale_modifier than the forward's: read as well
+    buf2 = gsr.render_gaussians(**kw)[2]
+    bkw4 = backward_kwargs(scene_t, cam, dict(kw, scale_modifier=1.0), buf2, dpix)
+    gsr.backward(**bkw4)
+    assert not bwd.last_call_recomputed_sigma3d
+
+
 def test_backward_accumulators_cleared_by_the_forward(oracle, cameras, scenes):
     """GsrBinning.backward_ws: the forward blend kernel's spare workgroups clear the accumulators of a backward workspace made for
     that frame, and the first backward() handed the frame's point_list takes that workspace and skips its own clear -- once: a second
