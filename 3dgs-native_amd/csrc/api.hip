@@ -279,6 +279,7 @@ void read_tuning()
         if (const char *e = getenv("GSR_BWD_XCD")) gsr_bwd_xcd_map = atoi(e);
         if (const char *e = getenv("GSR_FWD_XCD")) gsr_fwd_xcd_map = atoi(e) != 0;
         if (const char *e = getenv("GSR_BWD_NO_ORDER")) gsr_bwd_no_order = atoi(e) != 0;
+        if (const char *e = getenv("GSR_NO_DEPTH_PACK")) gsr_no_depth_pack = atoi(e) != 0;
         if (const char *e = getenv("GSR_NO_NARROWING")) gsr_no_narrowing = atoi(e) != 0;
         if (const char *e = getenv("GSR_FWD_NO_ORDER")) gsr_fwd_no_order = atoi(e) != 0;
     });
@@ -390,7 +391,9 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
     // previous frame in this workspace needed (its guess; four the first time).  If the guess turns out too low the launched
     // passes leave the data alone and all four are launched once the readback has said so.
     const int guess = (gsr_debug_flags & 256) ? 4 : depth_pass_guess(geom_ws);
-    HIP_TRY(gsr_launch_depth_sort(ws, N, s, guess));
+    // (packed depth items, scan_sort.hip: the tile grid at 6 bits per coordinate, the ids in 24)
+    const int pack_ok = (!gsr_no_depth_pack && cam.grid_x <= 63 && cam.grid_y <= 63 && N <= (1 << 24)) ? 1 : 0;
+    HIP_TRY(gsr_launch_depth_sort(ws, N, s, guess, pack_ok));
     HIP_TRY(hipEventSynchronize(rb->ev)); // D (and the pass count) are on the host; the GPU keeps sorting
     const int32_t last = *rb->pinned;
     int needed = 4;
@@ -402,7 +405,7 @@ int gsr_forward_count(const GsrScene *scene, const GsrCamera *camera, const GsrG
         }
         needed = gsr_depth_plan(lo, hi, (gsr_debug_flags & 256) ? 4 : 0).npass;
     }
-    if (needed > guess && !gsr_small_depth_path(N)) HIP_TRY(gsr_launch_depth_sort(ws, N, s, 4));
+    if (needed > guess && !gsr_small_depth_path(N)) HIP_TRY(gsr_launch_depth_sort(ws, N, s, 4, pack_ok));
     mark(st, 3, s);
     // (the depth-order offsets are made by gsr_forward_render, next to their one reader -- the expansion; the alternative path of
     // GSR_DEBUG bit 9 scans them here, into ws.doff)

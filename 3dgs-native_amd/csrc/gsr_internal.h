@@ -91,7 +91,9 @@ hipError_t gsr_launch_scan(const int32_t *in, const uint64_t *items, int32_t *ou
                            int64_t n, int mode, int32_t *total_out /* optional: receives the grand total */,
                            bool sums_per_256_ready /* mode 0: block_tmp already holds a sum per 256 items */, hipStream_t s,
                            const uint32_t *blk_minmax = nullptr, void *depth_ctl = nullptr /* mode 0: also derive the depth sort's DepthCtl */);
-hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes = 4 /* the last `launch_passes` of the four */);
+hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes = 4 /* the last `launch_passes` of the four */,
+                                 int pack_ok = 0 /* the sizes allow packed depth items (scan_sort.hip) */);
+extern int gsr_no_depth_pack; // GSR_NO_DEPTH_PACK: the last depth pass always gathers the rectangles by id (A/B, tests)
 hipError_t gsr_launch_scan_ctl_hist(const int32_t *tiles_touched, int32_t *point_offsets, const GeomWs &ws, int64_t n, int32_t *total_out, hipStream_t s);
 #define GSR_SMALL_SORT_N 8192          // up to this many Gaussians one workgroup sorts, carries and scans (scan_sort.hip)
 bool gsr_small_depth_path(int64_t n); // true: gsr_launch_depth_sort also writes the depth-order offsets (no separate scan)

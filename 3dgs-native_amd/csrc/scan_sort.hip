@@ -273,7 +273,31 @@ struct DepthPass {
     int launched_first;  // the host launched the passes launched_first .. 3 only (its guess from the previous frame): if this
                          // frame needs an earlier one (ctl->first < launched_first), every launched pass leaves the data alone
                          // and the host, told by the readback, launches all four
+    int pack_ok;         // the tile grid fits 6 bits per coordinate and the ids 24: see "packed depth items" below
 };
+// Packed depth items (late round 4).  The last depth pass hands the rest of the pipeline each Gaussian's id, tile rectangle and
+// tile count in depth order; fetching the rectangle BY ID at that point is a random 8-byte gather (121 MB moved for 8 needed at
+// C3, 20 us against 10 for a plain pass).  The first ACTIVE pass reads its items in id order, where the rectangle is a coalesced
+// read -- and once that pass has consumed the key's low byte, what is left of a two- or three-pass key (8 or 16 bits) shares a
+// 64-bit item with the rectangle at 6 bits per coordinate and a 24-bit id:
+//     [63:48] key >> 8   [47:24] x0 | y0 << 6 | x1 << 12 | y1 << 18   [23:0] id
+// So when the frame's plan has two or three passes (decided on the device, like the plan) and the sizes fit (pack_ok, decided by the
+// host), the first active pass writes such items, the later passes take their digits from bits 48.. and the last one unpacks instead
+// of gathering.  Same order, same outputs; a four-pass frame (16 + 24 + 24 + 8 > 64) and a one-pass frame (its only pass reads in
+// id order anyway) keep the plain items.
+__device__ __forceinline__ bool depth_items_packed(const DepthPass &dp, const DepthCtl &c) { return dp.pack_ok && c.npass >= 2 && c.npass <= 3; }
+__device__ __forceinline__ unsigned long long depth_item_pack(uint32_t key, unsigned long long rect_raw, uint32_t id)
+{
+    const uint32_t r24 = (uint32_t)(rect_raw & 63ull) | ((uint32_t)((rect_raw >> 16) & 63ull) << 6) | ((uint32_t)((rect_raw >> 32) & 63ull) << 12) |
+                         ((uint32_t)((rect_raw >> 48) & 63ull) << 18);
+    return ((unsigned long long)((key >> 8) & 0xFFFFu) << 48) | ((unsigned long long)r24 << 24) | (unsigned long long)(id & 0xFFFFFFu);
+}
+__device__ __forceinline__ unsigned long long depth_item_rect(unsigned long long item) // raw TileRect bits (4 x uint16)
+{
+    const uint32_t r24 = (uint32_t)(item >> 24) & 0xFFFFFFu;
+    return (unsigned long long)(r24 & 63u) | ((unsigned long long)((r24 >> 6) & 63u) << 16) | ((unsigned long long)((r24 >> 12) & 63u) << 32) |
+           ((unsigned long long)((r24 >> 18) & 63u) << 48);
+}
 template <bool DEPTH, int BITS, typename ItemT>
 __device__ __forceinline__ int radix_digit(ItemT item, int shift, uint32_t kmin, uint32_t krange)
 {
@@ -338,6 +362,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const ItemT *__restrict
         in = reinterpret_cast<const ItemT *>(dp.buf[rel & 1]);
         shift = 8 * rel;
         kmin = c.min_bits; krange = c.range;
+        if (depth_items_packed(dp, c)) { shift = 16 + 8 * (rel - 1); kmin = 0u; krange = 0xFFFFFFFFu; } // the digit sits in bits 48 + 8 (rel - 1) ..
         n = c.n_vis; // the first active pass dropped the culled ones: the later passes see the n_vis survivors only
         if ((int64_t)blockIdx.x * CHUNK >= n) return;
     }
@@ -473,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
     constexpr int NW = THREADS / 64; // waves per workgroup (GSR_RADIX_WIDE_WG: 8 waves of 8 items instead of 4 of 16 for the same chunk)
     constexpr int RADIX = 1 << BITS;
     __shared__ ItemT s_items[CHUNK];    // items reordered by digit
-    __shared__ unsigned long long s_rect[CARRY ? CHUNK : 1]; // CARRY: the items' rectangles (raw bits), reordered with them
+    __shared__ unsigned long long s_rect[(CARRY || DEPTH) ? CHUNK : 1]; // the items' rectangles (raw bits), reordered with them: CARRY, and the depth pass that packs them into the items
     __shared__ int s_wcnt[NW][RADIX];              // per-wave digit counts -> per-wave start offsets
     __shared__ int s_before[RADIX];                // items of each digit in earlier blocks
     __shared__ int s_total[RADIX];                 // items of each digit in all blocks
@@ -503,6 +528,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
     for (int z = blockIdx.x * THREADS + tid; z < zero_n; z += gridDim.x * THREADS) zero_acc[z] = 0;
     uint32_t kmin = 0u, krange = 0u;
     bool drop_culled = false;
+    bool packed = false, pack_now = false, unpack = false; // DEPTH: "packed depth items" above (all wave-uniform)
     int64_t n_load = n; // items readable in `in` (the index clamp of the loads)
     if constexpr (DEPTH) {
         const DepthCtl c = depth_ctl_load(dp.ctl, dp.force_npass);
@@ -513,6 +539,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
         out = reinterpret_cast<ItemT *>(dp.buf[(rel + 1) & 1]);
         shift = 8 * rel;
         kmin = c.min_bits; krange = c.range;
+        packed = depth_items_packed(dp, c);
+        pack_now = packed && rel == 0;            // this pass reads plain items and writes packed ones
+        if (packed && rel > 0) { shift = 16 + 8 * (rel - 1); kmin = 0u; krange = 0xFFFFFFFFu; unpack = true; } // packed items in
         // the first active pass reads all n items and drops the culled ones (they have no tiles: nothing downstream wants them);
         // the later passes move the n_vis survivors.  Everything this pass writes lands in [0, n_vis).
         drop_culled = rel == 0;
@@ -582,7 +611,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
 
     // pass 1: rank every item among equal digits of its wave, in index order
     ItemT item[RADIX_ITEMS];
-    unsigned long long rc[CARRY ? RADIX_ITEMS : 1]; // raw TileRect bits
+    unsigned long long rc[(CARRY || DEPTH) ? RADIX_ITEMS : 1]; // raw TileRect bits
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
     uint8_t low[LOWREC ? RADIX_ITEMS : 1]; // LOWREC: the item's first-pass digit
     bool valid_bits[RADIX_ITEMS];
@@ -597,11 +626,24 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
     if constexpr (CARRY) { // the random rectangle fetches are in flight during the ranking
         // raw 8-byte loads at a clamped index, no branch: as `valid ? rect[id] : {}` each fetch got its own exec-masked
         // block with a full wait behind it, i.e. RADIX_ITEMS serial random round trips
+        if (!unpack) {
 #pragma unroll
-        for (int r = 0; r < RADIX_ITEMS; ++r) {
-            const int64_t k = wave_base + r * 64 + lane;
-            const uint32_t id = k < n_load ? (uint32_t)item[r] : 0u;
-            rc[r] = reinterpret_cast<const unsigned long long *>(carry.rect)[id];
+            for (int r = 0; r < RADIX_ITEMS; ++r) {
+                const int64_t k = wave_base + r * 64 + lane;
+                const uint32_t id = k < n_load ? (uint32_t)item[r] : 0u;
+                rc[r] = reinterpret_cast<const unsigned long long *>(carry.rect)[id];
+            }
+        } else { // packed items carry their rectangle
+#pragma unroll
+            for (int r = 0; r < RADIX_ITEMS; ++r) rc[r] = depth_item_rect((unsigned long long)item[r]);
+        }
+    } else if constexpr (DEPTH) {
+        if (pack_now) { // the items are still in id order here (item k is Gaussian k): the rectangles are a coalesced read
+#pragma unroll
+            for (int r = 0; r < RADIX_ITEMS; ++r) {
+                const int64_t k = wave_base + r * 64 + lane;
+                rc[r] = reinterpret_cast<const unsigned long long *>(carry.rect)[k < n_load ? k : n_load - 1];
+            }
         }
     }
 #pragma unroll
@@ -686,6 +728,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
             s_items[slot] = item[r];
             if constexpr (LOWREC) s_low[slot] = low[r];
             if constexpr (CARRY) s_rect[slot] = rc[r];
+            else if constexpr (DEPTH) { if (pack_now) s_rect[slot] = rc[r]; }
         }
     }
     __syncthreads();
@@ -718,9 +761,16 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
                 }
                 if (rel == s_dcnt[d] - 1) fin.edge_last[e] = (int32_t)tile;
             } else if constexpr (CARRY) {
-                carry.id_sorted[pos] = (uint32_t)it; // the last depth pass: ids, rectangles and counts leave, not the items
+                carry.id_sorted[pos] = unpack ? ((uint32_t)it & 0xFFFFFFu) : (uint32_t)it; // the last depth pass: ids, rectangles and counts leave, not the items
             } else {
                 bool narrowed = false;
+                if constexpr (DEPTH) {
+                    if (pack_now) { // key = the reduced depth key this pass's digit came from; its low byte is spent
+                        const uint32_t key = min((uint32_t)(it >> 32) - kmin, krange);
+                        out[pos] = (ItemT)depth_item_pack(key, s_rect[slot], (uint32_t)it);
+                        narrowed = true;
+                    }
+                }
                 if constexpr (sizeof(ItemT) == 8 && !DEPTH) { // (uniform) the digit just sorted by leaves the item: see ScatterFinal
                     if (fin.narrow_id_bits) {
                         reinterpret_cast<uint32_t *>(out)[pos] = (uint32_t)(((it >> (shift + BITS)) << fin.narrow_id_bits) | (it & (((ItemT)1 << fin.narrow_id_bits) - 1)));
@@ -1320,6 +1370,7 @@ hipError_t gsr_launch_radix_pass(const void *in, void *out, int32_t *hist, int32
 }
 
 int gsr_no_narrowing = 0; // GSR_NO_NARROWING (gsr_internal.h)
+int gsr_no_depth_pack = 0; // GSR_NO_DEPTH_PACK (gsr_internal.h)
 
 // The LAST pass of the tile partition: histogram, then a scatter that writes point_list and the in-sight range boundaries
 // directly (ScatterFinal), and the edge fix-up.  `edge` holds 3 * (1 << bits) * nb int32 (gsr_radix_blocks(n) = nb).
@@ -1358,7 +1409,7 @@ hipError_t gsr_launch_scan_ctl_hist(const int32_t *tiles_touched, int32_t *point
 // and each Gaussian's tile rectangle and tile count carried to its sorted position.
 bool gsr_small_depth_path(int64_t n) { return n <= GSR_SMALL_SORT_N && !(gsr_debug_flags & 1024); } // GSR_DEBUG bit 10: never (tests)
 
-hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes)
+hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int launch_passes, int pack_ok)
 {
     if (n <= 0) return hipSuccess;
     launch_passes = std::min(4, std::max(1, launch_passes));
@@ -1370,14 +1421,14 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int
     const int zero_n = (int)gsr_radix_acc_ints(n);
     const ScatterCarry carry{ws.rect, ws.rect_sorted, ws.cnt_sorted, ws.id_sorted, n};
     for (int pass = 4 - launch_passes; pass < 4; ++pass) {
-        const DepthPass dp{(const DepthCtlRaw *)ws.depth_ctl, (gsr_debug_flags & 256) ? 4 : 0, pass, {ws.depth_item, ws.sort_tmp}, ws.acc_first, 4 - launch_passes};
+        const DepthPass dp{(const DepthCtlRaw *)ws.depth_ctl, (gsr_debug_flags & 256) ? 4 : 0, pass, {ws.depth_item, ws.sort_tmp}, ws.acc_first, 4 - launch_passes, pack_ok};
         // pass p accumulates into acc[p & 1] (both cleared by preprocess) and clears the other one for pass p + 1 -- except the
         // first ACTIVE pass, whose histogram and sums were made beside the id-order scan (gsr_launch_scan_ctl_hist) in acc_first.
         // The first LAUNCHED pass is either skipped by the plan or the first active one: its histogram kernel is not launched.
         const bool no_hist = pass == 4 - launch_passes;
         if (pass < 3)
             radix_pass_launch<8, uint64_t, false, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, ws.acc[(pass + 1) & 1], zero_n,
-                                                               ScatterCarry{}, ScatterFinal{}, s, dp, no_hist);
+                                                               carry /* (its rect array: the pass that packs the items reads it) */, ScatterFinal{}, s, dp, no_hist);
         else
             radix_pass_launch<8, uint64_t, true, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, nullptr, 0, carry, ScatterFinal{}, s, dp,
                                                               no_hist);

@@ -64,6 +64,20 @@ def test_wide_tile_items_over_two_passes(narrowing):
     assert " passed" in r.stdout
 
 
+def test_depth_sort_with_plain_items_through_every_pass():
+    """A frame whose depth keys need two or three passes (most frames) and whose tile grid fits 6 bits per coordinate gets PACKED depth
+    items from the first active pass on (key remainder | rectangle | id: the last pass unpacks instead of gathering rectangles by id).
+    GSR_NO_DEPTH_PACK=1 keeps the plain items and the gather (the path of rounds 1-3, still taken by four-pass frames and large
+    grids); with GSR_DEBUG bit 10 the multi-kernel depth stage also serves the small fuzz scenes.  Both against the oracle."""
+    for pack in ("1", "0"):
+        env = dict(os.environ, GSR_NO_DEPTH_PACK=pack, GSR_DEBUG="1024", GSR_FUZZ_CASES="96", GSR_NEEDLE_CASES="4")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                            os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+                            "-k", "not png and not workspace and not full_size_configs[C5]"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, pack + r.stdout[-3000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout
+
+
 def test_two_training_steps_with_the_forward_xcd_map():
     """GSR_FWD_XCD=1 (neighbouring tiles of the forward blend on one XCD) cannot host the spare workgroups that clear the backward's
     accumulators; the forward must then clear them another way, or the SECOND step's gradients would carry the first step's sums
