@@ -488,7 +488,10 @@ struct ScatterFinal {
     int low_bits;                // ... and its digit width (0: the items hold the whole tile id)
 };
 
-template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false, int THREADS = 256, bool LOWREC = false>
+// PACKCAP (DEPTH, not CARRY): the host allows packed depth items (DepthPass.pack_ok), so this pass may be the one that packs them and
+// needs the rectangles' LDS image -- 32 KB at 4096-item chunks, which a frame that cannot pack (C5's 120 x 68 grid) must not pay for.
+template <int RADIX_ITEMS, int BITS, typename ItemT, bool CARRY = false, bool FINAL = false, bool DEPTH = false, int THREADS = 256, bool LOWREC = false,
+          bool PACKCAP = false>
 __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__restrict__ in, ItemT *__restrict__ out,
                                                             const int32_t *__restrict__ hist, const int32_t *__restrict__ acc,
                                                             int64_t n, int shift, int nb, int sb, bool prefixed, int32_t *__restrict__ zero_acc,
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
     constexpr int NW = THREADS / 64; // waves per workgroup (GSR_RADIX_WIDE_WG: 8 waves of 8 items instead of 4 of 16 for the same chunk)
     constexpr int RADIX = 1 << BITS;
     __shared__ ItemT s_items[CHUNK];    // items reordered by digit
-    __shared__ unsigned long long s_rect[(CARRY || DEPTH) ? CHUNK : 1]; // the items' rectangles (raw bits), reordered with them: CARRY, and the depth pass that packs them into the items
+    __shared__ unsigned long long s_rect[(CARRY || PACKCAP) ? CHUNK : 1]; // the items' rectangles (raw bits), reordered with them: CARRY, and the depth pass that packs them into the items
     __shared__ int s_wcnt[NW][RADIX];              // per-wave digit counts -> per-wave start offsets
     __shared__ int s_before[RADIX];                // items of each digit in earlier blocks
     __shared__ int s_total[RADIX];                 // items of each digit in all blocks
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
         shift = 8 * rel;
         kmin = c.min_bits; krange = c.range;
         packed = depth_items_packed(dp, c);
-        pack_now = packed && rel == 0;            // this pass reads plain items and writes packed ones
+        pack_now = PACKCAP && packed && rel == 0; // this pass reads plain items and writes packed ones (pack_ok implies a PACKCAP launch)
         if (packed && rel > 0) { shift = 16 + 8 * (rel - 1); kmin = 0u; krange = 0xFFFFFFFFu; unpack = true; } // packed items in
         // the first active pass reads all n items and drops the culled ones (they have no tiles: nothing downstream wants them);
         // the later passes move the n_vis survivors.  Everything this pass writes lands in [0, n_vis).
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
 
     // pass 1: rank every item among equal digits of its wave, in index order
     ItemT item[RADIX_ITEMS];
-    unsigned long long rc[(CARRY || DEPTH) ? RADIX_ITEMS : 1]; // raw TileRect bits
+    unsigned long long rc[(CARRY || PACKCAP) ? RADIX_ITEMS : 1]; // raw TileRect bits
     int rank[RADIX_ITEMS]; // rank within (wave, digit)
     uint8_t low[LOWREC ? RADIX_ITEMS : 1]; // LOWREC: the item's first-pass digit
     bool valid_bits[RADIX_ITEMS];
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
 #pragma unroll
             for (int r = 0; r < RADIX_ITEMS; ++r) rc[r] = depth_item_rect((unsigned long long)item[r]);
         }
-    } else if constexpr (DEPTH) {
+    } else if constexpr (PACKCAP) {
         if (pack_now) { // the items are still in id order here (item k is Gaussian k): the rectangles are a coalesced read
 #pragma unroll
             for (int r = 0; r < RADIX_ITEMS; ++r) {
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
             s_items[slot] = item[r];
             if constexpr (LOWREC) s_low[slot] = low[r];
             if constexpr (CARRY) s_rect[slot] = rc[r];
-            else if constexpr (DEPTH) { if (pack_now) s_rect[slot] = rc[r]; }
+            else if constexpr (PACKCAP) { if (pack_now) s_rect[slot] = rc[r]; }
         }
     }
     __syncthreads();
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(const ItemT *__r
                 carry.id_sorted[pos] = unpack ? ((uint32_t)it & 0xFFFFFFu) : (uint32_t)it; // the last depth pass: ids, rectangles and counts leave, not the items
             } else {
                 bool narrowed = false;
-                if constexpr (DEPTH) {
+                if constexpr (PACKCAP) {
                     if (pack_now) { // key = the reduced depth key this pass's digit came from; its low byte is spent
                         const uint32_t key = min((uint32_t)(it >> 32) - kmin, krange);
                         out[pos] = (ItemT)depth_item_pack(key, s_rect[slot], (uint32_t)it);
@@ -1290,7 +1293,7 @@ static PassGeom pass_geom(int64_t n)
     return g;
 }
 
-template <int BITS, typename ItemT, bool CARRY, bool FINAL, bool DEPTH = false, bool LOWREC = false>
+template <int BITS, typename ItemT, bool CARRY, bool FINAL, bool DEPTH = false, bool LOWREC = false, bool PACKCAP = false>
 static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_t *acc, int64_t n, int shift, int32_t *zero_acc, int zero_n,
                               const ScatterCarry &carry, const ScatterFinal &fin, hipStream_t s, const DepthPass &dp = DepthPass{}, bool hist_ready = false)
 {
@@ -1307,13 +1310,13 @@ static void radix_pass_launch(const ItemT *in, ItemT *out, int32_t *hist, int32_
     }
     if (g.prefixed) hipLaunchKernelGGL(radix_superscan_kernel, dim3(4), dim3(1024), 0, s, acc, (g.nb + g.sb - 1) / g.sb, dp);
     if (g.tier == 0) {
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_TINY_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH, 256, LOWREC>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n, shift,
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_TINY_CHUNK / 256, BITS, ItemT, CARRY, FINAL, DEPTH, 256, LOWREC, PACKCAP>), dim3(g.nb), dim3(256), 0, s, in, out, hist, acc, n, shift,
                            g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else if (g.tier == 1) {
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / GSR_RADIX_SMALL_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_SMALL_WG, LOWREC>), dim3(g.nb), dim3(GSR_RADIX_SMALL_WG),
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_SMALL_CHUNK / GSR_RADIX_SMALL_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_SMALL_WG, LOWREC, PACKCAP>), dim3(g.nb), dim3(GSR_RADIX_SMALL_WG),
                            0, s, in, out, hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     } else {
-        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / GSR_RADIX_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_WG, LOWREC>), dim3(g.nb), dim3(GSR_RADIX_WG), 0, s, in, out,
+        hipLaunchKernelGGL((radix_scatter_kernel<GSR_RADIX_CHUNK / GSR_RADIX_WG, BITS, ItemT, CARRY, FINAL, DEPTH, GSR_RADIX_WG, LOWREC, PACKCAP>), dim3(g.nb), dim3(GSR_RADIX_WG), 0, s, in, out,
                            hist, acc, n, shift, g.nb, g.sb, g.prefixed, zero_acc, zero_n, carry, fin, dp);
     }
     if constexpr (FINAL)
@@ -1426,9 +1429,12 @@ hipError_t gsr_launch_depth_sort(const GeomWs &ws, int64_t n, hipStream_t s, int
         // first ACTIVE pass, whose histogram and sums were made beside the id-order scan (gsr_launch_scan_ctl_hist) in acc_first.
         // The first LAUNCHED pass is either skipped by the plan or the first active one: its histogram kernel is not launched.
         const bool no_hist = pass == 4 - launch_passes;
-        if (pass < 3)
+        if (pass < 3 && pack_ok)
+            radix_pass_launch<8, uint64_t, false, false, true, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, ws.acc[(pass + 1) & 1], zero_n,
+                                                                            carry /* (its rect array: the pass that packs the items reads it) */, ScatterFinal{}, s, dp, no_hist);
+        else if (pass < 3)
             radix_pass_launch<8, uint64_t, false, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, ws.acc[(pass + 1) & 1], zero_n,
-                                                               carry /* (its rect array: the pass that packs the items reads it) */, ScatterFinal{}, s, dp, no_hist);
+                                                               ScatterCarry{}, ScatterFinal{}, s, dp, no_hist);
         else
             radix_pass_launch<8, uint64_t, true, false, true>(ws.depth_item, ws.sort_tmp, ws.hist, ws.acc[pass & 1], n, 0, nullptr, 0, carry, ScatterFinal{}, s, dp,
                                                               no_hist);
